@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference (run in the build container only).
+
+Imports the reference's PennyLane-free modules from /root/reference (stein_utils,
+bayesian_network, utils, ksd_vi, born_machine_classical_sim), pushes fixed inputs through
+them and stores inputs + outputs as small .npz files next to this script.  The reference
+never travels to the GPU box; only these data files do.  Nothing here copies reference
+source -- the files hold numbers only.
+
+    python tests/golden/make_golden.py            # everything (n=8 synthetic takes ~2 min)
+    python tests/golden/make_golden.py --skip-n8
+"""
+import argparse
+import io
+import os
+import sys
+import contextlib
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)
+
+import stein_utils as ref_su                      # noqa: E402  (reference)
+import bayesian_network as ref_bn                 # noqa: E402  (reference)
+import utils as ref_utils                         # noqa: E402  (reference)
+
+from tensornetworks_amd.bayesian_network import synthetic_network, pack_network  # noqa: E402
+
+
+def ref_scores_and_gram(bn, latents, observed, x_dict, length_scale=1.0, rows=None):
+    n = len(latents)
+    outs = ref_utils.generate_all_binary_outcomes(n)
+    S = [ref_su.get_score_function_sp_for_z(bn, x_dict, z, latents, observed) for z in outs]
+    kfun = partial(ref_su.base_hamming_kernel_torch, num_vars=n, length_scale=length_scale)
+    N = len(outs)
+    rows = list(range(N)) if rows is None else rows
+    K = np.zeros((len(rows), N))
+    for a, i in enumerate(rows):
+        for j in range(N):
+            K[a, j] = ref_su.get_stein_kernel_kp_value(outs[i], outs[j], x_dict, bn, latents, observed,
+                                                       kfun, S[i], S[j]).item()
+    pxz = np.array([ref_su.compute_prob_joint_xz(bn, x_dict, z, latents, observed) for z in outs])
+    return torch.stack(S).numpy(), K, pxz
+
+
+def ref_loss_and_grad(K_unused, bn, latents, observed, x_dict, q, length_scale=1.0):
+    """KSD loss and d loss/d q through the reference's own double loop + torch autograd
+    (restating the epoch body of ksd_vi_quantum.py:123-150 on a fixed q)."""
+    n = len(latents)
+    outs = ref_utils.generate_all_binary_outcomes(n)
+    S = {z: ref_su.get_score_function_sp_for_z(bn, x_dict, z, latents, observed) for z in outs}
+    kfun = partial(ref_su.base_hamming_kernel_torch, num_vars=n, length_scale=length_scale)
+    qt = torch.tensor(q, dtype=torch.float64, requires_grad=True)
+    tot = torch.tensor(0.0, dtype=torch.float64)
+    for i, zi in enumerate(outs):
+        for j, zj in enumerate(outs):
+            kp = ref_su.get_stein_kernel_kp_value(zi, zj, x_dict, bn, latents, observed, kfun, S[zi], S[zj])
+            tot = tot + qt[i] * qt[j] * kp
+    loss = torch.sqrt(tot.clamp(min=1e-12))
+    loss.backward()
+    return tot.item(), loss.item(), qt.grad.numpy().copy()
+
+
+def to_ref_bn(our_bn):
+    """Rebuild one of our BayesianNetwork objects as a *reference* BayesianNetwork (same CPT numbers)."""
+    bn = ref_bn.BayesianNetwork()
+    for nm in our_bn.nodes:
+        pa = list(our_bn.parents[nm]) if nm in our_bn.parents else None
+        bn.add_node(nm, cpt=our_bn.cpts[nm], parent_names=pa or None)
+    return bn
+
+
+def sprinkler_case(tag, bn, x_dict):
+    latents, observed = ['C', 'S', 'R'], ['W']
+    S, K, pxz = ref_scores_and_gram(bn, latents, observed, x_dict)
+    post, p_obs = bn.get_true_posterior(latents, x_dict)
+    outs = ref_utils.generate_all_binary_outcomes(3)
+    posterior = np.array([post[z] for z in outs])
+    prior_d = bn.get_prior_distribution(latents)
+    prior = np.array([prior_d[z] for z in outs])
+    g = torch.Generator().manual_seed(1234)
+    qr = torch.rand(8, dtype=torch.float64, generator=g)
+    qr = (qr / qr.sum()).numpy()
+    qu = np.full(8, 1.0 / 8)
+    out = dict(S=S, K=K, pxz=pxz, posterior=posterior, prior=prior, p_observed=p_obs,
+               q_rand=qr, q_uniform=qu, x_value=np.array([x_dict['W']]))
+    for nm, q in (("rand", qr), ("uniform", qu), ("posterior", posterior)):
+        s, l, gq = ref_loss_and_grad(K, bn, latents, observed, x_dict, q)
+        out[f"ksd2_{nm}"], out[f"loss_{nm}"], out[f"dLdq_{nm}"] = s, l, gq
+    pk = pack_network(bn, latents, x_dict)
+    out.update({f"pack_{k}": v for k, v in pk.items()})
+    np.savez(os.path.join(HERE, f"sprinkler_{tag}.npz"), **out)
+    print(f"sprinkler_{tag}: P(obs)={p_obs:.6f} loss_uniform={out['loss_uniform']:.12f}")
+
+
+def synthetic_case(n, seed, rows=None):
+    ours, latents, observed, x_dict = synthetic_network(n, seed)
+    bn = to_ref_bn(ours)
+    S, K, pxz = ref_scores_and_gram(bn, latents, observed, x_dict, rows=rows)
+    pk = pack_network(ours, latents, x_dict)
+    out = dict(S=S, K=K, pxz=pxz, n=np.array([n]), seed=np.array([seed]),
+               rows=np.arange(2 ** n) if rows is None else np.array(rows))
+    out.update({f"pack_{k}": v for k, v in pk.items()})
+    np.savez(os.path.join(HERE, f"synthetic_n{n}_s{seed}.npz"), **out)
+    print(f"synthetic n={n} seed={seed}: |K|max={np.abs(K).max():.6e}")
+
+
+def two_node_kat():
+    bn = ref_bn.BayesianNetwork()
+    bn.add_node('A', cpt={(): {0: 0.8, 1: 0.2}})
+    bn.add_node('B', cpt={(0,): {0: 0.7, 1: 0.3}, (1,): {0: 0.4, 1: 0.6}}, parent_names=['A'])
+    x = {'B': 1}
+    S, K, pxz = ref_scores_and_gram(bn, ['A'], ['B'], x)
+    np.savez(os.path.join(HERE, "two_node.npz"), S=S, K=K, pxz=pxz)
+    print("two_node:", S.ravel(), K.ravel())
+
+
+def classical_trace():
+    """Seeded 5-epoch trace of the reference's *classical* KSD trainer (ksd_vi.py:62-216,
+    conditioning_dim=0 => no Dropout): per-epoch q (before the update) and loss_ksd.
+    Pins the KSD loop shared with ksd_vi_quantum.py:110-145."""
+    import ksd_vi as ref_ksd                         # reference
+    torch.manual_seed(7)
+    bn = ref_bn.get_sprinkler_network(False)
+    vi = ref_ksd.KSDVariationalInference(bn, ['C', 'S', 'R'], ['W'],
+                                         born_machine_config={'use_logits': True, 'conditioning_dim': 0})
+    qs = []
+    orig = vi.born_machine.get_probabilities
+
+    def spy(x_condition=None):
+        out = orig(x_condition=x_condition)
+        qs.append(out.detach().squeeze().to(torch.float64).numpy().copy())
+        return out
+    vi.born_machine.get_probabilities = spy
+    with contextlib.redirect_stdout(io.StringIO()):
+        hist = vi.train({'W': 1}, num_epochs=5, lr_born_machine=0.01, verbose=False,
+                        true_posterior_for_tvd=None, entropy_weight=0.0)
+    # the trainer calls get_probabilities once per epoch for the loss (plus possibly entropy)
+    losses = np.array(hist['loss_ksd'])
+    q_used = []
+    it = iter(qs)
+    for l in losses:
+        q_used.append(next(it))
+        # skip the extra forward made by entropy() if any
+    np.savez(os.path.join(HERE, "classical_trace.npz"), q_all=np.array(qs), loss_ksd=losses)
+    print("classical_trace: losses", losses, "forwards recorded", len(qs))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-n8", action="store_true")
+    args = ap.parse_args()
+    two_node_kat()
+    sprinkler_case("w1", ref_bn.get_sprinkler_network(False), {'W': 1})
+    sprinkler_case("w0", ref_bn.get_sprinkler_network(False), {'W': 0})
+    for sd in (0, 1, 2):
+        np.random.seed(sd)
+        sprinkler_case(f"rand{sd}", ref_bn.get_sprinkler_network(True), {'W': 1})
+    for n in (4, 5, 6):
+        synthetic_case(n, 0)
+    synthetic_case(5, 1)
+    classical_trace()
+    if not args.skip_n8:
+        # 32 of the 256 rows of K (each row = 256 reference k_p calls), full S
+        synthetic_case(8, 0, rows=list(range(0, 256, 8)))
