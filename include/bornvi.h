@@ -1,0 +1,177 @@
+/*
+ * bornvi.h -- C ABI of libbornvi_hip.so, the MI355X (gfx950) backend for the KSD
+ * variational-inference hot path of sozoluffy/TensorNetworks.
+ *
+ * The reference has no FFI: its boundary for this path is the Python API of
+ * quantum_born_machine.py / stein_utils.py / ksd_vi_quantum.py.  Each entry point below
+ * states which reference lines it replaces; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary;
+ *   - return value: 0 (BORNVI_OK) or a negative bornvi_status; text via bornvi_last_error();
+ *   - every pointer documented "dev" is device memory owned by the CALLER (PyTorch);
+ *     the library never frees it and keeps no reference after the call returns;
+ *   - every op is asynchronous on the hipStream_t passed as `stream` (0 = null stream);
+ *   - workspace is caller-provided; bornvi_*_workspace_bytes gives the size for the full
+ *     batch, a smaller workspace makes the library process the batch in chunks
+ *     (it must hold at least one circuit);
+ *   - a handle is bound to one device and is not thread-safe; distinct handles are.
+ *   - outcome index i <-> bitstring bin(i).zfill(n): bit position 0 of the tuple is the MOST
+ *     significant bit of i and is wire 0 of the circuit (utils.py:77-91).
+ */
+#ifndef BORNVI_H
+#define BORNVI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BORNVI_VERSION 100 /* 0.1.0 */
+
+typedef struct bornvi_ctx* bornvi_handle;
+typedef void* bornvi_stream; /* hipStream_t */
+
+typedef enum {
+  BORNVI_OK = 0,
+  BORNVI_ERR_INVALID = -1,     /* bad argument */
+  BORNVI_ERR_HIP = -2,         /* a HIP runtime call failed (text has the HIP error) */
+  BORNVI_ERR_WORKSPACE = -3,   /* workspace too small for a single circuit */
+  BORNVI_ERR_UNSUPPORTED = -4  /* size outside the supported range */
+} bornvi_status;
+
+/* ansatz_type strings of QuantumBornMachine (quantum_born_machine.py:31-38, :57-128) */
+typedef enum {
+  BORNVI_ANSATZ_HARDWARE_EFFICIENT = 0, /* quantum_born_machine.py:58-87  */
+  BORNVI_ANSATZ_ALL_TO_ALL = 1,         /* quantum_born_machine.py:90-111 */
+  BORNVI_ANSATZ_BASIC = 2               /* quantum_born_machine.py:114-128 */
+} bornvi_ansatz;
+
+int bornvi_version(void);
+
+/* One handle per device.  Holds the compiled circuit plans (small device buffers). */
+int bornvi_create(int device_ordinal, bornvi_handle* out);
+void bornvi_destroy(bornvi_handle h);
+/* Text of the last error on this handle (valid until the next call on it). h may be NULL
+ * for errors of bornvi_create. */
+const char* bornvi_last_error(bornvi_handle h);
+
+/* Tuning knobs of the circuit planner (clears the plan cache): "tile_bits" (4..13, amplitudes per
+ * LDS tile = 2^tile_bits), "low_bits" (0..8, contiguous 16-byte elements per HBM run = 2^low_bits),
+ * "max_threads" (64..512). */
+int bornvi_set_option(bornvi_handle h, const char* name, long long value);
+
+/* num_ansatz_params (quantum_born_machine.py:31-38) and gate count of the QNode. */
+int bornvi_num_params(int ansatz, int n, int layers);
+int bornvi_num_gates(int ansatz, int n, int layers);
+
+/* ---- circuit -> Born probabilities (replaces the PennyLane QNode `pqc`, -------------------
+ * quantum_born_machine.py:58-128, as called by get_probabilities :132-137).
+ * thetas dev [batch, P] float64;  probs dev [batch, 2^n] float64, lexicographic, wire 0 = MSB. */
+size_t bornvi_circuit_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers, int batch);
+int bornvi_circuit_probs(bornvi_handle h, int ansatz, int n, int layers, int batch,
+                         const double* thetas, double* probs,
+                         void* workspace, size_t workspace_bytes, bornvi_stream stream);
+
+/* ---- parameter-shift evaluations (replaces diff_method="parameter-shift", ------------------
+ * quantum_born_machine.py:58,:90,:114, triggered by loss.backward() ksd_vi_quantum.py:150).
+ * For p in [p_begin, p_end): circuits theta + pi/2 e_p and theta - pi/2 e_p.
+ * probs dev [(include_base ? 1 : 0) + 2 (p_end - p_begin), 2^n]: optional base row first,
+ * then rows (+p_begin, -p_begin, +p_begin+1, -p_begin+1, ...).  theta dev [P] float64.
+ * The batch for bornvi_circuit_workspace_bytes is that row count. */
+int bornvi_paramshift_probs(bornvi_handle h, int ansatz, int n, int layers,
+                            const double* theta, int p_begin, int p_end, int include_base,
+                            double* probs, void* workspace, size_t workspace_bytes,
+                            bornvi_stream stream);
+
+/* grad[p - p_begin] = 1/2 * sum_z dLdq[z] (q(theta + pi/2 e_p)[z] - q(theta - pi/2 e_p)[z]).
+ * dLdq dev [2^n], grad dev [p_end - p_begin].  Workspace: the circuit workspace for batch
+ * 2 (p_end - p_begin) plus 2 (p_end - p_begin) * 2^n * 8 bytes (bornvi_paramshift_grad_workspace_bytes). */
+size_t bornvi_paramshift_grad_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers,
+                                              int p_begin, int p_end);
+int bornvi_paramshift_grad(bornvi_handle h, int ansatz, int n, int layers,
+                           const double* theta, const double* dLdq, int p_begin, int p_end,
+                           double* grad, void* workspace, size_t workspace_bytes,
+                           bornvi_stream stream);
+
+/* ---- un-fused gate application on a batch of statevectors (the gate-apply micro-benchmark of
+ * BASELINE.json; one HBM round trip per gate = 32 * 2^n bytes per state).
+ * state dev [batch, 2^n] complex128 (re, im interleaved), updated in place.
+ * U: HOST pointer to 8 doubles (u00.re, u00.im, u01.re, u01.im, u10.re, ..., u11.im). */
+int bornvi_gate1q_apply(bornvi_handle h, int n, long long batch, double* state, int wire,
+                        const double* U, bornvi_stream stream);
+int bornvi_cnot_apply(bornvi_handle h, int n, long long batch, double* state, int control,
+                      int target, bornvi_stream stream);
+/* q = |psi|^2 : state dev [batch, 2^n] complex128 -> probs dev [batch, 2^n] float64. */
+int bornvi_born_probs(bornvi_handle h, int n, long long batch, const double* state, double* probs,
+                      bornvi_stream stream);
+
+/* ---- score function (replaces stein_utils.compute_prob_joint_xz :58-112 and ----------------
+ * get_score_function_sp_for_z :115-136 evaluated for all 2^n latent states, i.e.
+ * KSDVariationalInference._precompute_all_s_p ksd_vi_quantum.py:70-75, on top of
+ * BayesianNetwork.get_joint_probability bayesian_network.py:111-146).
+ * All pointers in the descriptor are DEVICE pointers (layout: pack_network() in
+ * tensornetworks_amd/bayesian_network.py). */
+typedef struct {
+  int32_t num_nodes;        /* V <= 64 */
+  int32_t max_parents;      /* row length of `parents` (8) */
+  const int32_t* role;      /* [V] latent position 0..n-1 | -1 observed=0 | -2 observed=1 | -3 summed out */
+  const int32_t* n_parents; /* [V] */
+  const int32_t* parents;   /* [V, max_parents] node indices, CPT key order */
+  const int32_t* cpt_off;   /* [V] offset in doubles into cpt */
+  const double* cpt;        /* table[config][value]; config = parent values, first parent MSB */
+} bornvi_bn_desc;
+/* S dev [2^n, n] (row z, column b = tuple position b), pxz dev [2^n] or NULL. */
+int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, double* S,
+                           double* pxz, bornvi_stream stream);
+
+/* ---- Stein-kernel Gram matrix (replaces the N^2 calls of get_stein_kernel_kp_value, --------
+ * stein_utils.py:138-197 with base_hamming_kernel_torch :30-55, made in
+ * ksd_vi_quantum.py:125-141).  K dev [2^n, 2^n] float64 row-major. */
+int bornvi_stein_gram_build(bornvi_handle h, int n, double length_scale, const double* S,
+                            double* K, bornvi_stream stream);
+
+/* k_p(z_i, z_j | x) for M explicit pairs -- the batched form of ONE call of
+ * stein_utils.get_stein_kernel_kp_value (:138-197): zi, zj dev int64 [M] outcome indices,
+ * si, sj dev [M, n] the score rows sp_at_z1 / sp_at_z2 supplied by the caller, out dev [M]. */
+int bornvi_stein_kp_pairs(bornvi_handle h, int n, double length_scale, long long M,
+                          const long long* zi, const long long* zj, const double* si,
+                          const double* sj, double* out, bornvi_stream stream);
+
+/* ---- quadratic form (replaces the accumulation sum_ij q_i q_j k_p, ksd_vi_quantum.py:123-142).
+ * Q dev [B, 2^n]; ksd2 dev [B] = q_b^T K q_b; Y dev [B, 2^n] = K q_b or NULL.
+ * Deterministic (no atomics).  Workspace: bornvi_stein_quadform_workspace_bytes. */
+size_t bornvi_stein_quadform_workspace_bytes(bornvi_handle h, int n, int B);
+int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B,
+                          double* ksd2, double* Y, void* workspace, size_t workspace_bytes,
+                          bornvi_stream stream);
+
+/* Matrix-free y = K_p q via the Kronecker structure of K_p (needed where the dense Gram does
+ * not fit: n = 20 would be 8 TiB).  q, y dev [2^n]; ksd2 dev [1]. */
+size_t bornvi_stein_matvec_kron_workspace_bytes(bornvi_handle h, int n);
+int bornvi_stein_matvec_kron(bornvi_handle h, int n, double length_scale, const double* S,
+                             const double* q, double* y, double* ksd2, void* workspace,
+                             size_t workspace_bytes, bornvi_stream stream);
+
+/* ---- loss and gradient assembly (replaces ksd_vi_quantum.py:144-145 and the autograd chain
+ * of :150): loss = sqrt(max(ksd2, 1e-12)); dLdq = y / loss (0 when the clamp is active);
+ * grad[p] = 1/2 dLdq . (q+_p - q-_p).
+ * shifted dev [2 * n_shift, 2^n] rows (+p, -p) as bornvi_paramshift_probs lays them out;
+ * y dev [2^n]; ksd2 dev [1]; loss_out dev [1]; dLdq_out dev [2^n] or NULL; grad dev [n_shift]. */
+int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_shift,
+                           const double* y, const double* ksd2, double* loss_out,
+                           double* dLdq_out, double* grad, bornvi_stream stream);
+
+/* ---- introspection (host only, no GPU needed): serialised execution plan of a circuit ------
+ * (passes / stages / fused gates) as uint32 words; used by the CPU tests to check the
+ * planner against the oracle.  Returns the number of words (writes min(cap, words)). */
+long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
+                               size_t cap_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BORNVI_H */

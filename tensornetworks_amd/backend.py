@@ -1,0 +1,235 @@
+"""Tensor-level wrappers over the bornvi C ABI (include/bornvi.h).
+
+PyTorch owns every buffer (inputs, outputs, workspaces) and the stream; this module only checks
+shapes / dtypes / devices and passes raw pointers.  Everything here needs an MI355X: tensors must
+live on a 'cuda' (PyTorch-ROCm) device.  There is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _ext
+from ._ext import ANSATZ_IDS, BornviError
+
+_workspaces = {}
+
+# Cap for the circuit workspace (bytes); larger batches are processed in chunks by the library.
+WORKSPACE_CAP = int(os.environ.get("BORNVI_WORKSPACE_CAP", str(48 << 30)))
+
+
+def compute_device(preferred=None):
+    """The GPU this process computes on: `preferred` if it is a cuda device, else cuda:LOCAL_RANK / current."""
+    if preferred is not None:
+        d = torch.device(preferred)
+        if d.type == "cuda":
+            return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+    if not torch.cuda.is_available():
+        raise BornviError("no MI355X visible: the bornvi backend has no CPU fallback "
+                          "(torch.cuda.is_available() is False)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def ansatz_id(ansatz_type):
+    """quantum_born_machine.py:31-38/:113: any string other than the two named ones selects 'basic'."""
+    return ANSATZ_IDS.get(ansatz_type, ANSATZ_IDS["basic"])
+
+
+def num_params(ansatz_type, n, layers):
+    return _ext.lib().bornvi_num_params(ansatz_id(ansatz_type), n, layers)
+
+
+def _ws(dev, nbytes, tag="main"):
+    key = (dev.index, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _workspaces[key] = None
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _workspaces[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def _chk(t, dtype, dev, name):
+    if t.dtype != dtype or t.device != dev or not t.is_contiguous():
+        raise BornviError(f"{name}: expected contiguous {dtype} on {dev}, got {t.dtype} on {t.device}")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def set_option(dev, name, value):
+    h = _ext.handle_for(dev)
+    h.call("bornvi_set_option", name.encode(), int(value))
+
+
+# ---- circuits -------------------------------------------------------------------------------------
+def circuit_probs(ansatz_type, n, layers, thetas):
+    """thetas float64 [B, P] on a cuda device -> probs float64 [B, 2^n]."""
+    dev = thetas.device
+    h = _ext.handle_for(dev)
+    aid = ansatz_id(ansatz_type)
+    P = num_params(ansatz_type, n, layers)
+    if thetas.dim() != 2 or thetas.shape[1] != P:
+        raise BornviError(f"thetas must be [batch, {P}]")
+    _chk(thetas, torch.float64, dev, "thetas")
+    B = thetas.shape[0]
+    probs = torch.empty((B, 1 << n), dtype=torch.float64, device=dev)
+    need = h.size("bornvi_circuit_workspace_bytes", aid, n, layers, B)
+    ws = _ws(dev, min(need, max(WORKSPACE_CAP, h.size("bornvi_circuit_workspace_bytes", aid, n, layers, 1))))
+    h.call("bornvi_circuit_probs", aid, n, layers, B, _ptr(thetas), _ptr(probs), _ptr(ws), ws.numel(),
+           _ext.stream_ptr(dev))
+    return probs
+
+
+def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=True, out=None):
+    """theta float64 [P] -> probs [(1 if include_base) + 2 (p_end - p_begin), 2^n]:
+    optional base row, then (+p, -p) rows for p in [p_begin, p_end)."""
+    dev = theta.device
+    h = _ext.handle_for(dev)
+    aid = ansatz_id(ansatz_type)
+    _chk(theta, torch.float64, dev, "theta")
+    B = (1 if include_base else 0) + 2 * (p_end - p_begin)
+    if out is None:
+        out = torch.empty((B, 1 << n), dtype=torch.float64, device=dev)
+    else:
+        _chk(out, torch.float64, dev, "out")
+        if out.numel() != B << n:
+            raise BornviError("out has the wrong size")
+    if B == 0:
+        return out
+    need = h.size("bornvi_circuit_workspace_bytes", aid, n, layers, B)
+    ws = _ws(dev, min(need, max(WORKSPACE_CAP, h.size("bornvi_circuit_workspace_bytes", aid, n, layers, 1))))
+    h.call("bornvi_paramshift_probs", aid, n, layers, _ptr(theta), int(p_begin), int(p_end),
+           1 if include_base else 0, _ptr(out), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
+    return out
+
+
+def paramshift_grad(ansatz_type, n, layers, theta, dLdq, p_begin, p_end):
+    """grad[p - p_begin] = 1/2 dLdq . (q(theta + pi/2 e_p) - q(theta - pi/2 e_p)), float64."""
+    dev = theta.device
+    h = _ext.handle_for(dev)
+    aid = ansatz_id(ansatz_type)
+    _chk(theta, torch.float64, dev, "theta")
+    _chk(dLdq, torch.float64, dev, "dLdq")
+    ns = p_end - p_begin
+    grad = torch.empty(ns, dtype=torch.float64, device=dev)
+    if ns == 0:
+        return grad
+    shifted = paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=False)
+    # dot products on the device: reuse the finishing kernel with ksd2 = 1 (loss = 1, scale = 1/2)
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    h.call("bornvi_ksd_grad_finish", n, _ptr(shifted), ns, _ptr(dLdq), _ptr(one), None, None, _ptr(grad),
+           _ext.stream_ptr(dev))
+    return grad
+
+
+def gate1q_apply(state, n, wire, U):
+    """In-place one-qubit gate on state complex128 [B, 2^n] (one HBM round trip)."""
+    dev = state.device
+    h = _ext.handle_for(dev)
+    _chk(state, torch.complex128, dev, "state")
+    Uh = np.ascontiguousarray(np.asarray(U, dtype=np.complex128).reshape(4)).view(np.float64)
+    arr = (C.c_double * 8)(*Uh.tolist())
+    h.call("bornvi_gate1q_apply", n, state.numel() >> n, _ptr(state), int(wire), arr, _ext.stream_ptr(dev))
+    return state
+
+
+def cnot_apply(state, n, control, target):
+    dev = state.device
+    h = _ext.handle_for(dev)
+    _chk(state, torch.complex128, dev, "state")
+    h.call("bornvi_cnot_apply", n, state.numel() >> n, _ptr(state), int(control), int(target), _ext.stream_ptr(dev))
+    return state
+
+
+def born_probs(state, n):
+    dev = state.device
+    h = _ext.handle_for(dev)
+    _chk(state, torch.complex128, dev, "state")
+    probs = torch.empty(state.shape, dtype=torch.float64, device=dev)
+    h.call("bornvi_born_probs", n, state.numel() >> n, _ptr(state), _ptr(probs), _ext.stream_ptr(dev))
+    return probs
+
+
+# ---- Stein ---------------------------------------------------------------------------------------
+def score_from_packed(packed, n, dev):
+    """packed: dict from bayesian_network.pack_network -> (S [2^n, n], pxz [2^n]) float64 on dev."""
+    h = _ext.handle_for(dev)
+    t = {k: torch.as_tensor(np.ascontiguousarray(v)).to(dev) for k, v in packed.items()}
+    desc = _ext.BnDesc(int(t["role"].numel()), int(t["parents"].shape[1]), t["role"].data_ptr(),
+                       t["n_parents"].data_ptr(), t["parents"].data_ptr(), t["cpt_off"].data_ptr(),
+                       t["cpt"].data_ptr())
+    S = torch.empty((1 << n, n), dtype=torch.float64, device=dev)
+    pxz = torch.empty(1 << n, dtype=torch.float64, device=dev)
+    h.call("bornvi_score_from_cpts", C.byref(desc), n, _ptr(S), _ptr(pxz), _ext.stream_ptr(dev))
+    torch.cuda.current_stream(dev).synchronize()   # `t` (descriptor arrays) must outlive the kernel
+    return S, pxz
+
+
+def stein_gram(S, n, length_scale=1.0):
+    dev = S.device
+    h = _ext.handle_for(dev)
+    _chk(S, torch.float64, dev, "S")
+    K = torch.empty((1 << n, 1 << n), dtype=torch.float64, device=dev)
+    h.call("bornvi_stein_gram_build", n, float(length_scale), _ptr(S), _ptr(K), _ext.stream_ptr(dev))
+    return K
+
+
+def stein_kp_pairs(n, length_scale, zi, zj, si, sj):
+    dev = si.device
+    h = _ext.handle_for(dev)
+    for t, dt, nm in ((zi, torch.int64, "zi"), (zj, torch.int64, "zj"), (si, torch.float64, "si"), (sj, torch.float64, "sj")):
+        _chk(t, dt, dev, nm)
+    M = zi.numel()
+    out = torch.empty(M, dtype=torch.float64, device=dev)
+    h.call("bornvi_stein_kp_pairs", n, float(length_scale), M, _ptr(zi), _ptr(zj), _ptr(si), _ptr(sj), _ptr(out),
+           _ext.stream_ptr(dev))
+    return out
+
+
+def stein_quadform(K, Q, n, want_y=True):
+    """Q [B, 2^n] (or [2^n]) -> (ksd2 [B], Y [B, 2^n] or None)."""
+    dev = K.device
+    h = _ext.handle_for(dev)
+    _chk(K, torch.float64, dev, "K")
+    Q2 = Q.reshape(-1, 1 << n)
+    _chk(Q2, torch.float64, dev, "Q")
+    B = Q2.shape[0]
+    ksd2 = torch.empty(B, dtype=torch.float64, device=dev)
+    Y = torch.empty_like(Q2) if want_y else None
+    ws = _ws(dev, h.size("bornvi_stein_quadform_workspace_bytes", n, B), "qf")
+    h.call("bornvi_stein_quadform", n, _ptr(K), _ptr(Q2), B, _ptr(ksd2), _ptr(Y) if want_y else None, _ptr(ws),
+           ws.numel(), _ext.stream_ptr(dev))
+    return ksd2, Y
+
+
+def stein_matvec_kron(S, q, n, length_scale=1.0):
+    """Matrix-free (ksd2 [1], y = K_p q [2^n])."""
+    dev = S.device
+    h = _ext.handle_for(dev)
+    _chk(S, torch.float64, dev, "S")
+    _chk(q, torch.float64, dev, "q")
+    y = torch.empty(1 << n, dtype=torch.float64, device=dev)
+    ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
+    ws = _ws(dev, h.size("bornvi_stein_matvec_kron_workspace_bytes", n), "kron")
+    h.call("bornvi_stein_matvec_kron", n, float(length_scale), _ptr(S), _ptr(q), _ptr(y), _ptr(ksd2), _ptr(ws),
+           ws.numel(), _ext.stream_ptr(dev))
+    return ksd2, y
+
+
+def ksd_grad_finish(n, shifted, n_shift, y, ksd2, want_dldq=False):
+    """-> (loss [1], grad [n_shift], dLdq [2^n] or None); see bornvi_ksd_grad_finish."""
+    dev = y.device
+    h = _ext.handle_for(dev)
+    loss = torch.empty(1, dtype=torch.float64, device=dev)
+    grad = torch.empty(n_shift, dtype=torch.float64, device=dev)
+    dldq = torch.empty(1 << n, dtype=torch.float64, device=dev) if want_dldq else None
+    h.call("bornvi_ksd_grad_finish", n, _ptr(shifted) if n_shift else None, int(n_shift), _ptr(y), _ptr(ksd2),
+           _ptr(loss), _ptr(dldq) if want_dldq else None, _ptr(grad) if n_shift else None, _ext.stream_ptr(dev))
+    return loss, grad, dldq

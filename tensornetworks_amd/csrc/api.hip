@@ -1,0 +1,390 @@
+// C ABI of libbornvi_hip.so (include/bornvi.h): argument checking, plan cache, workspace carving,
+// kernel sequencing.  No exceptions leave this file; HIP errors are captured into the handle.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+
+#include "bornvi.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace bornvi;
+
+namespace {
+
+struct DevPlan {
+  Plan plan;
+  uint32_t* d_words = nullptr;
+};
+
+thread_local std::string g_create_error;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct bornvi_ctx {
+  int device = 0;
+  std::string err;
+  PlanOptions opt;
+  std::map<std::tuple<int, int, int>, std::unique_ptr<DevPlan>> plans;  // (ansatz | -1 = kron, n, layers)
+  size_t max_lds_prepared = 0;
+};
+
+namespace {
+
+int fail(bornvi_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return fail(h, BORNVI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
+  auto key = std::make_tuple(ansatz, n, layers);
+  auto it = h->plans.find(key);
+  if (it != h->plans.end()) { *out = it->second.get(); return BORNVI_OK; }
+  auto dp = std::make_unique<DevPlan>();
+  std::string msg;
+  const bool ok = (ansatz == -1) ? make_kron_plan(n, h->opt, dp->plan, msg)
+                                 : make_plan(ansatz, n, layers, h->opt, dp->plan, msg);
+  if (!ok) return fail(h, BORNVI_ERR_UNSUPPORTED, msg);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMalloc((void**)&dp->d_words, dp->plan.words.size() * sizeof(uint32_t)));
+  HIPCHK(h, hipMemcpy(dp->d_words, dp->plan.words.data(), dp->plan.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (dp->plan.lds_bytes() > h->max_lds_prepared) {
+    HIPCHK(h, prepare_circuit_kernel(dp->plan.lds_bytes()));
+    h->max_lds_prepared = dp->plan.lds_bytes();
+  }
+  *out = dp.get();
+  h->plans[key] = std::move(dp);
+  return BORNVI_OK;
+}
+
+// bytes one circuit needs in the workspace: its fused-gate matrices + two ping-pong states
+size_t per_circuit_bytes(const Plan& p) {
+  size_t b = (size_t)p.n_fused * 64;
+  if (p.n_passes > 1) b += 2 * ((size_t)16 << p.n);
+  return b;
+}
+
+// Runs all passes of `dp` for `bc` circuits.  in0: input state of pass 0 (or null for |0..0>);
+// bufA/bufB: ping-pong buffers; final_state / final_probs: destination of the last pass.
+int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA, void* bufB, void* final_state,
+               double* final_probs, const double* gates, long long gate_stride, hipStream_t st) {
+  const Plan& p = dp->plan;
+  const void* in = in0;
+  for (int i = 0; i < p.n_passes; ++i) {
+    const bool last = (i == p.n_passes - 1);
+    void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
+    HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, bc, in, out, final_probs, gates, gate_stride, st));
+    in = out;
+  }
+  return BORNVI_OK;
+}
+
+int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batch, const double* thetas,
+                  int shift_mode, int p_begin, int include_base, double* probs, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (batch < 0 || (!thetas) || (!probs && batch > 0)) return fail(h, BORNVI_ERR_INVALID, "null pointer or negative batch");
+  if (batch == 0) return BORNVI_OK;
+  DevPlan* dp = nullptr;
+  int rc = get_plan(h, ansatz, n, layers, &dp);
+  if (rc) return rc;
+  const Plan& p = dp->plan;
+  const size_t pcb = per_circuit_bytes(p);
+  if (!ws || ws_bytes < 512) return fail(h, BORNVI_ERR_WORKSPACE, "workspace missing");
+  // carve: [gates | stateA | stateB], each region 256-byte aligned
+  long long bc_max = (long long)((ws_bytes - 512) / pcb);
+  if (bc_max > batch) bc_max = batch;
+  if (bc_max > 65535) bc_max = 65535;  // gridDim.y
+  if (bc_max < 1) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small for one circuit");
+  char* base = (char*)ws;
+  double* gates = (double*)base;
+  const size_t gates_bytes = align_up((size_t)bc_max * p.n_fused * 64, 256);
+  const size_t state_bytes = align_up((size_t)bc_max * ((size_t)16 << n), 256);
+  void* bufA = base + gates_bytes;
+  void* bufB = base + gates_bytes + state_bytes;
+  HIPCHK(h, hipSetDevice(h->device));
+  for (long long c0 = 0; c0 < batch; c0 += bc_max) {
+    const int bc = (int)((batch - c0 < bc_max) ? batch - c0 : bc_max);
+    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, include_base, c0, bc, gates, st));
+    rc = run_passes(h, dp, bc, nullptr, bufA, bufB, nullptr, probs + (c0 << n), gates, (long long)p.n_fused * 8, st);
+    if (rc) return rc;
+  }
+  return BORNVI_OK;
+}
+
+bool valid_n_for_dense(int n) { return n >= 1 && n <= 17; }
+
+}  // namespace
+
+extern "C" {
+
+int bornvi_version(void) { return BORNVI_VERSION; }
+
+int bornvi_create(int device_ordinal, bornvi_handle* out) {
+  if (!out) return BORNVI_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return BORNVI_ERR_HIP;
+  }
+  if (device_ordinal < 0 || device_ordinal >= count) {
+    g_create_error = "device ordinal out of range";
+    return BORNVI_ERR_INVALID;
+  }
+  bornvi_ctx* h = new (std::nothrow) bornvi_ctx();
+  if (!h) { g_create_error = "out of host memory"; return BORNVI_ERR_INVALID; }
+  h->device = device_ordinal;
+  *out = h;
+  return BORNVI_OK;
+}
+
+void bornvi_destroy(bornvi_handle h) {
+  if (!h) return;
+  for (auto& kv : h->plans)
+    if (kv.second && kv.second->d_words) (void)hipFree(kv.second->d_words);
+  delete h;
+}
+
+const char* bornvi_last_error(bornvi_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
+  if (!h || !name) return BORNVI_ERR_INVALID;
+  PlanOptions o = h->opt;
+  if (!std::strcmp(name, "tile_bits")) o.kmax = (int)value;
+  else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;
+  else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
+  else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
+  if (o.kmax < 4 || o.kmax > 13 || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
+      (o.max_threads & (o.max_threads - 1)))
+    return fail(h, BORNVI_ERR_INVALID, "option value out of range");
+  h->opt = o;
+  for (auto& kv : h->plans)
+    if (kv.second && kv.second->d_words) (void)hipFree(kv.second->d_words);
+  h->plans.clear();
+  return BORNVI_OK;
+}
+
+int bornvi_num_params(int ansatz, int n, int layers) { return num_params(ansatz, n, layers); }
+
+int bornvi_num_gates(int ansatz, int n, int layers) {
+  std::vector<Gate> g;
+  if (!build_gate_list(ansatz, n, layers, g)) return -1;
+  return (int)g.size();
+}
+
+size_t bornvi_circuit_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers, int batch) {
+  if (!h || batch < 0) return 0;
+  DevPlan* dp = nullptr;
+  if (get_plan(h, ansatz, n, layers, &dp)) return 0;
+  const Plan& p = dp->plan;
+  size_t b = 512 + align_up((size_t)batch * p.n_fused * 64, 256);
+  if (p.n_passes > 1) b += 2 * align_up((size_t)batch * ((size_t)16 << n), 256);
+  return b;
+}
+
+int bornvi_circuit_probs(bornvi_handle h, int ansatz, int n, int layers, int batch, const double* thetas,
+                         double* probs, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  return circuit_batch(h, ansatz, n, layers, batch, thetas, 0, 0, 0, probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int bornvi_paramshift_probs(bornvi_handle h, int ansatz, int n, int layers, const double* theta, int p_begin,
+                            int p_end, int include_base, double* probs, void* workspace, size_t workspace_bytes,
+                            bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  const int P = num_params(ansatz, n, layers);
+  if (P < 0 || p_begin < 0 || p_end < p_begin || p_end > P) return fail(h, BORNVI_ERR_INVALID, "parameter range out of bounds");
+  const long long batch = (include_base ? 1 : 0) + 2ll * (p_end - p_begin);
+  return circuit_batch(h, ansatz, n, layers, batch, theta, 1, p_begin, include_base ? 1 : 0, probs, workspace,
+                       workspace_bytes, (hipStream_t)stream);
+}
+
+size_t bornvi_paramshift_grad_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers, int p_begin, int p_end) {
+  if (!h || p_end < p_begin) return 0;
+  const int nb = 2 * (p_end - p_begin);
+  const size_t c = bornvi_circuit_workspace_bytes(h, ansatz, n, layers, nb);
+  if (!c) return 0;
+  return c + align_up((size_t)nb * ((size_t)8 << n), 256);
+}
+
+int bornvi_paramshift_grad(bornvi_handle h, int ansatz, int n, int layers, const double* theta, const double* dLdq,
+                           int p_begin, int p_end, double* grad, void* workspace, size_t workspace_bytes,
+                           bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!theta || !dLdq || !grad) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  const int ns = p_end - p_begin;
+  if (ns == 0) return BORNVI_OK;
+  const size_t probs_bytes = align_up((size_t)2 * ns * ((size_t)8 << n), 256);
+  if (!workspace || workspace_bytes < probs_bytes + 512) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+  double* shifted = (double*)workspace;
+  int rc = bornvi_paramshift_probs(h, ansatz, n, layers, theta, p_begin, p_end, 0, shifted,
+                                   (char*)workspace + probs_bytes, workspace_bytes - probs_bytes, stream);
+  if (rc) return rc;
+  HIPCHK(h, launch_shift_dot(shifted, ns, dLdq, nullptr, n, grad, nullptr, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_gate1q_apply(bornvi_handle h, int n, long long batch, double* state, int wire, const double* U,
+                        bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!state || !U || n < 1 || n > 40 || wire < 0 || wire >= n || batch < 0) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (batch == 0) return BORNVI_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_gate1q(state, n, batch, wire, U, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_cnot_apply(bornvi_handle h, int n, long long batch, double* state, int control, int target,
+                      bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!state || n < 2 || n > 40 || control < 0 || control >= n || target < 0 || target >= n || control == target || batch < 0)
+    return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (batch == 0) return BORNVI_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_cnot(state, n, batch, control, target, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_born_probs(bornvi_handle h, int n, long long batch, const double* state, double* probs, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!state || !probs || n < 0 || n > 40 || batch < 0) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (batch == 0) return BORNVI_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_born_probs(state, probs, n, batch, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, double* S, double* pxz, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!bn || !S || n < 1 || n > 30) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (bn->num_nodes < 1 || bn->num_nodes > 64 || bn->max_parents < 1 || !bn->role || !bn->n_parents || !bn->parents ||
+      !bn->cpt_off || !bn->cpt)
+    return fail(h, BORNVI_ERR_INVALID, "bad network descriptor");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_score(*bn, n, S, pxz, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_stein_gram_build(bornvi_handle h, int n, double length_scale, const double* S, double* K, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!S || !K) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17 (8 * 4^n bytes)");
+  if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_gram_build(n, length_scale, S, K, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_stein_kp_pairs(bornvi_handle h, int n, double length_scale, long long M, const long long* zi,
+                          const long long* zj, const double* si, const double* sj, double* out, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (n < 1 || n > 30 || M < 0 || (M > 0 && (!zi || !zj || !si || !sj || !out))) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_kp_pairs(n, length_scale, M, zi, zj, si, sj, out, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+size_t bornvi_stein_quadform_workspace_bytes(bornvi_handle h, int n, int B) {
+  (void)h; (void)B;
+  if (n < 1 || n > 30) return 0;
+  return align_up(quadform_partials(n) * sizeof(double), 256);
+}
+
+int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B, double* ksd2, double* Y,
+                          void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!K || !Q || !ksd2 || B < 0) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  if (!workspace || workspace_bytes < bornvi_stein_quadform_workspace_bytes(h, n, B))
+    return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+  HIPCHK(h, hipSetDevice(h->device));
+  const long long N = 1ll << n;
+  for (int b = 0; b < B; ++b)
+    HIPCHK(h, launch_quadform(n, K, Q + b * N, Y ? Y + b * N : nullptr, ksd2 + b, (double*)workspace, nullptr, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+size_t bornvi_stein_matvec_kron_workspace_bytes(bornvi_handle h, int n) {
+  if (!h || n < 1 || n > 30) return 0;
+  DevPlan* dp = nullptr;
+  if (get_plan(h, -1, n, 0, &dp)) return 0;
+  const size_t npk = (size_t)(n + 2) / 2;
+  const size_t st = align_up(npk * ((size_t)16 << n), 256);
+  const size_t nbuf = dp->plan.n_passes >= 3 ? 3 : (dp->plan.n_passes == 2 ? 2 : 1);
+  return 256 + nbuf * st + align_up(kron_partials(n) * sizeof(double), 256);
+}
+
+int bornvi_stein_matvec_kron(bornvi_handle h, int n, double length_scale, const double* S, const double* q, double* y,
+                             double* ksd2, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!S || !q || !ksd2) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
+  const size_t need = bornvi_stein_matvec_kron_workspace_bytes(h, n);
+  if (!need) return h->err.empty() ? fail(h, BORNVI_ERR_UNSUPPORTED, "unsupported n") : BORNVI_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < need) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+  DevPlan* dp = nullptr;
+  int rc = get_plan(h, -1, n, 0, &dp);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int npk = (n + 2) / 2;
+  const size_t stb = align_up((size_t)npk * ((size_t)16 << n), 256);
+  char* base = (char*)workspace;
+  double* gate = (double*)base;
+  void* X = base + 256;
+  void* A = base + 256 + stb;
+  void* Bf = base + 256 + 2 * stb;
+  const int np = dp->plan.n_passes;
+  double* partials = (double*)(base + 256 + (np >= 3 ? 3 : (np == 2 ? 2 : 1)) * stb);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_kron_pack(n, length_scale, S, q, (double*)X, gate, st));
+  // X -> (A -> B -> A ...) -> X : the last pass writes back into X (dead after pass 0; with a single
+  // pass each workgroup owns a whole state and reads it completely before writing).
+  rc = run_passes(h, dp, npk, X, A, Bf, X, nullptr, gate, 0, st);
+  if (rc) return rc;
+  HIPCHK(h, launch_kron_combine(n, S, q, (const double*)X, y, partials, ksd2, st));
+  return BORNVI_OK;
+}
+
+int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_shift, const double* y,
+                           const double* ksd2, double* loss_out, double* dLdq_out, double* grad, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!y || !ksd2 || n < 1 || n > 30 || n_shift < 0 || (n_shift > 0 && (!shifted || !grad)))
+    return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (dLdq_out || loss_out) HIPCHK(h, launch_dldq(y, ksd2, n, dLdq_out, loss_out, st));
+  HIPCHK(h, launch_shift_dot(shifted, n_shift, y, ksd2, n, grad, nullptr, st));
+  return BORNVI_OK;
+}
+
+long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
+  PlanOptions opt;
+  if (tile_bits > 0) opt.kmax = tile_bits;
+  Plan p;
+  std::string msg;
+  const bool ok = (ansatz == -1) ? make_kron_plan(n, opt, p, msg) : make_plan(ansatz, n, layers, opt, p, msg);
+  if (!ok) return -1;
+  if (out) {
+    const size_t c = p.words.size() < cap_words ? p.words.size() : cap_words;
+    std::memcpy(out, p.words.data(), c * sizeof(uint32_t));
+  }
+  return (long long)p.words.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// Launchers implemented in kernels_circuit.hip / kernels_stein.hip, called from api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "bornvi.h"
+
+namespace bornvi {
+
+// ---- circuit ------------------------------------------------------------------------------------
+hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
+                              int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
+                              double* gates, hipStream_t st);
+hipError_t prepare_circuit_kernel(size_t lds_bytes);
+hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, int batch,
+                               const void* in, void* out, double* probs, const double* gates,
+                               long long gate_stride, hipStream_t st);
+hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st);
+hipError_t launch_cnot(double* state, int n, long long batch, int control, int target, hipStream_t st);
+hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st);
+hipError_t launch_shift_dot(const double* shifted, int n_shift, const double* w, const double* ksd2, int n,
+                            double* grad, double* loss_out, hipStream_t st);
+hipError_t launch_dldq(const double* y, const double* ksd2, int n, double* dLdq, double* loss_out, hipStream_t st);
+
+// ---- Stein ----------------------------------------------------------------------------------------
+hipError_t launch_score(const bornvi_bn_desc& bn, int n, double* S, double* pxz, hipStream_t st);
+hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, hipStream_t st);
+hipError_t launch_kp_pairs(int n, double length_scale, long long M, const long long* zi, const long long* zj,
+                           const double* si, const double* sj, double* out, hipStream_t st);
+size_t quadform_partials(int n);  // number of per-workgroup partial sums
+hipError_t launch_quadform(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
+                           double* partials, double* ytmp, hipStream_t st);
+// matrix-free mat-vec helpers
+hipError_t launch_kron_pack(int n, double length_scale, const double* S, const double* q,
+                            double* packed /*complex [(n+2)/2, 2^n]*/, double* gate /*[8]*/, hipStream_t st);
+hipError_t launch_kron_combine(int n, const double* S, const double* q, const double* packed, double* y,
+                               double* partials, double* ksd2, hipStream_t st);
+size_t kron_partials(int n);
+
+}  // namespace bornvi

@@ -1,0 +1,439 @@
+// Statevector kernels for gfx950 (MI355X): fused-gate matrices, the LDS-tiled circuit pass,
+// the un-fused one-gate kernels (gate-apply micro-benchmark) and Born probabilities.
+//
+// Data layout: a state is 2^n complex128 (re, im interleaved = double2), outcome index i with
+// wire 0 the MOST significant bit (utils.py:77-91 / qml.probs order).  Between passes the
+// amplitudes live in HBM in a pass-specific bit permutation chosen by the planner (plan.hpp);
+// only the last pass writes the canonical order (as probabilities).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace bornvi {
+
+// LDS index swizzle: xor-fold the upper nibbles into the low nibble.  Linear over GF(2)
+// (swz(a ^ b) == swz(a) ^ swz(b)), its own inverse, keeps bits >= 4.  With it a 16-lane
+// ds_read_b128 group is conflict-free whenever its lane bits land on LDS bit positions with
+// distinct residues mod 4 (the planner's order_for_banks), including register wires on bits 0-3.
+__device__ __forceinline__ uint32_t swz(uint32_t l) { return l ^ (((l >> 4) ^ (l >> 8) ^ (l >> 12)) & 15u); }
+
+// ------------------------------------------------------------------------------------------------
+// fused one-qubit matrices: U = G_{ne-1} ... G_1 G_0 (G_0 applied first), PennyLane conventions
+// RX = exp(-i t X/2), RY = exp(-i t Y/2), RZ = diag(e^{-it/2}, e^{it/2}); H.
+// Row-major complex: m[0..1] = u00, m[2..3] = u01, m[4..5] = u10, m[6..7] = u11.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void elem_matrix(uint32_t kind, double t, double (&m)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = 0.0;
+  if (kind == G_H) {
+    const double h = 0.70710678118654752440;
+    m[0] = h; m[2] = h; m[4] = h; m[6] = -h;
+    return;
+  }
+  double s, c;
+  sincos(t / 2.0, &s, &c);
+  if (kind == G_RX) { m[0] = c; m[3] = -s; m[5] = -s; m[6] = c; }
+  else if (kind == G_RY) { m[0] = c; m[2] = -s; m[4] = s; m[6] = c; }
+  else { m[0] = c; m[1] = -s; m[6] = c; m[7] = s; }  // RZ
+}
+
+__global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const double* __restrict__ thetas,
+                                   long long theta_stride, int shift_mode, int p_begin, int include_base,
+                                   long long b_offset, int batch, double* __restrict__ gates) {
+  const uint32_t nf = plan[PH_NFUSED];
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)batch * nf) return;
+  const long long b = idx / nf;
+  const uint32_t f = (uint32_t)(idx % nf);
+  const uint32_t* fw = plan + plan[PH_OFF_FUSED] + f * FUSED_WORDS;
+  const long long bg = b + b_offset;
+  uint32_t pshift = 0xfffffffeu;
+  double shift = 0.0;
+  if (shift_mode) {
+    const long long bb = bg - include_base;
+    if (bb >= 0) { pshift = (uint32_t)(p_begin + (bb >> 1)); shift = (bb & 1) ? -M_PI_2 : M_PI_2; }
+  }
+  const double* th = thetas + (shift_mode ? 0 : bg * theta_stride);
+  double U[8] = {1, 0, 0, 0, 0, 0, 1, 0};
+  const uint32_t ne = fw[1];
+  for (uint32_t e = 0; e < ne; ++e) {
+    const uint32_t kind = fw[2 + 2 * e], par = fw[3 + 2 * e];
+    double t = 0.0;
+    if (par != 0xffffffffu) { t = th[par]; if (par == pshift) t += shift; }
+    double M[8], R[8];
+    elem_matrix(kind, t, M);
+    // R = M * U
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int cidx = 0; cidx < 2; ++cidx) {
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double ar = M[(r * 2 + q) * 2], ai = M[(r * 2 + q) * 2 + 1];
+          const double br = U[(q * 2 + cidx) * 2], bi = U[(q * 2 + cidx) * 2 + 1];
+          re += ar * br - ai * bi;
+          im += ar * bi + ai * br;
+        }
+        R[(r * 2 + cidx) * 2] = re; R[(r * 2 + cidx) * 2 + 1] = im;
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) U[i] = R[i];
+  }
+  double* dst = gates + (b * nf + f) * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[i] = U[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// register-level micro-ops on the 16 amplitudes a thread holds (static indices only: runtime-indexed
+// arrays would go to scratch)
+// ------------------------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void op_u1(double (&ar)[16], double (&ai)[16], const double (&U)[8]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j & (1 << I)) continue;
+    const int j1 = j | (1 << I);
+    const double x0r = ar[j], x0i = ai[j], x1r = ar[j1], x1i = ai[j1];
+    ar[j] = U[0] * x0r - U[1] * x0i + U[2] * x1r - U[3] * x1i;
+    ai[j] = U[0] * x0i + U[1] * x0r + U[2] * x1i + U[3] * x1r;
+    ar[j1] = U[4] * x0r - U[5] * x0i + U[6] * x1r - U[7] * x1i;
+    ai[j1] = U[4] * x0i + U[5] * x0r + U[6] * x1i + U[7] * x1r;
+  }
+}
+
+template <int C, int T>
+__device__ __forceinline__ void op_cx_rr(double (&ar)[16], double (&ai)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (!(j & (1 << C)) || (j & (1 << T))) continue;
+    const int j1 = j | (1 << T);
+    const double tr = ar[j], ti = ai[j];
+    ar[j] = ar[j1]; ai[j] = ai[j1];
+    ar[j1] = tr; ai[j1] = ti;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void op_cx_ar(double (&ar)[16], double (&ai)[16], bool c) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j & (1 << T)) continue;
+    const int j1 = j | (1 << T);
+    const double a0r = ar[j], a0i = ai[j], a1r = ar[j1], a1i = ai[j1];
+    ar[j] = c ? a1r : a0r; ai[j] = c ? a1i : a0i;
+    ar[j1] = c ? a0r : a1r; ai[j1] = c ? a0i : a1i;
+  }
+}
+
+__device__ __forceinline__ uint32_t deposit_bits(uint32_t v, int from, int to, const uint32_t* __restrict__ pos) {
+  uint32_t o = 0;
+  for (int j = from; j < to; ++j) o |= ((v >> j) & 1u) << pos[j];
+  return o;
+}
+
+// One pass of the circuit program over one 2^k-amplitude tile per workgroup.
+// grid = (2^(n-k) tiles, circuits); block = plan threads; dynamic LDS = 2^k * 16 bytes.
+__global__ __launch_bounds__(512) void circuit_pass_kernel(
+    const uint32_t* __restrict__ plan, uint32_t pass_off, const double2* __restrict__ in,
+    double2* __restrict__ out, double* __restrict__ probs, const double* __restrict__ gates,
+    long long gate_stride, long long state_stride) {
+  extern __shared__ double2 tile[];
+  const uint32_t* __restrict__ P = plan + pass_off;
+  const uint32_t flags = P[PW_FLAGS];
+  const int k = (int)P[PW_K], n = (int)P[PW_N];
+  const int nstages = (int)P[PW_NSTAGES];
+  const int lo_in = (int)P[PW_LO_IN], lo_out = (int)P[PW_LO_OUT];
+  const uint32_t t = threadIdx.x, T = blockDim.x;
+  const int tau = 31 - __clz((int)T);
+  const int kt = tau < k ? tau : k;  // index bits supplied by the thread id
+  const uint32_t g = blockIdx.x;
+  const long long b = blockIdx.y;
+  const uint32_t ksize = 1u << k;
+  const int niter = 1 << (k - kt);
+
+  // ---- tile in: HBM (pass-specific bit order) -> LDS, or |0...0> ---------------------------------
+  if (flags & PASS_INIT) {
+    for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
+  } else if (t < ksize) {
+    uint32_t gin = 0;
+    for (int m = 0; m < n - k; ++m) gin |= ((g >> m) & 1u) << P[PW_IN_GPHYS + m];
+    const double2* __restrict__ src = in + b * state_stride + gin;
+    const uint32_t thr = (t & ((1u << lo_in) - 1u)) | deposit_bits(t, lo_in, kt, P + PW_IN_PHYS);
+#pragma unroll 4
+    for (int i = 0; i < niter; ++i) {
+      uint32_t itp = 0;
+      for (int j = kt; j < k; ++j) itp |= (((uint32_t)i >> (j - kt)) & 1u) << P[PW_IN_PHYS + j];
+      const uint32_t u = t | ((uint32_t)i << kt);
+      tile[swz(u)] = src[thr | itp];
+    }
+  }
+  __syncthreads();
+
+  // ---- stages: 2^r amplitudes per thread in registers, one LDS round trip each -----------------------
+  const uint32_t* __restrict__ S = P + PW_STAGES;
+  for (int s = 0; s < nstages; ++s) {
+    const uint32_t hdr = S[0];
+    const int r = (int)(hdr & 0xffu);
+    const int nops = (int)((hdr >> 8) & 0xffu);
+    const uint32_t nwords = hdr >> 16;
+    if (t < (1u << (k - r))) {
+      const uint32_t rho = S[1];
+      uint32_t base = 0;
+      for (int j = 0; j < k - r; ++j) base |= ((t >> j) & 1u) << ((S[2 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
+      const uint32_t pb = swz(base);
+      const uint32_t e = base | (g << k);  // extended index: LDS bits then workgroup bits
+      uint32_t sr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sr[i] = (i < r) ? swz(1u << ((rho >> (8 * i)) & 0xffu)) : 0u;
+      const int nreg = 1 << r;
+      double ar[16], ai[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t off = ((j & 1) ? sr[0] : 0u) ^ ((j & 2) ? sr[1] : 0u) ^ ((j & 4) ? sr[2] : 0u) ^ ((j & 8) ? sr[3] : 0u);
+        if (j < nreg) { const double2 v = tile[pb ^ off]; ar[j] = v.x; ai[j] = v.y; }
+        else { ar[j] = 0.0; ai[j] = 0.0; }
+      }
+      const uint32_t* __restrict__ op = S + STAGE_HDR_WORDS;
+      for (int o = 0; o < nops; ++o) {
+        const uint32_t w = *op++;
+        const uint32_t kind = w & 15u, a = (w >> 4) & 63u, bb = (w >> 10) & 63u, idx = w >> 16;
+        if (kind == OP_U1) {
+          const double* __restrict__ Ug = gates + b * gate_stride + (size_t)idx * 8;
+          double U[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) U[i] = Ug[i];
+          switch (a) {
+            case 0: op_u1<0>(ar, ai, U); break;
+            case 1: op_u1<1>(ar, ai, U); break;
+            case 2: op_u1<2>(ar, ai, U); break;
+            default: op_u1<3>(ar, ai, U); break;
+          }
+        } else if (kind == OP_CX_RR) {
+          switch (a * 4 + bb) {
+            case 1: op_cx_rr<0, 1>(ar, ai); break;
+            case 2: op_cx_rr<0, 2>(ar, ai); break;
+            case 3: op_cx_rr<0, 3>(ar, ai); break;
+            case 4: op_cx_rr<1, 0>(ar, ai); break;
+            case 6: op_cx_rr<1, 2>(ar, ai); break;
+            case 7: op_cx_rr<1, 3>(ar, ai); break;
+            case 8: op_cx_rr<2, 0>(ar, ai); break;
+            case 9: op_cx_rr<2, 1>(ar, ai); break;
+            case 11: op_cx_rr<2, 3>(ar, ai); break;
+            case 12: op_cx_rr<3, 0>(ar, ai); break;
+            case 13: op_cx_rr<3, 1>(ar, ai); break;
+            case 14: op_cx_rr<3, 2>(ar, ai); break;
+            default: break;
+          }
+        } else if (kind == OP_CX_AR) {
+          const bool c = (e >> a) & 1u;
+          switch (bb) {
+            case 0: op_cx_ar<0>(ar, ai, c); break;
+            case 1: op_cx_ar<1>(ar, ai, c); break;
+            case 2: op_cx_ar<2>(ar, ai, c); break;
+            default: op_cx_ar<3>(ar, ai, c); break;
+          }
+        } else {  // OP_SIGNQ: product of CZ gates = (-1)^{q(x)}, q a quadratic form over index bits
+          uint32_t acc = 0;
+          for (int q = 0; q < n; ++q) {
+            const uint32_t row = op[q];
+            acc ^= ((e >> q) & 1u) & (uint32_t)__popc(e & row);
+          }
+          const uint32_t qbits = op[48] ^ (0u - (acc & 1u));
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const uint32_t sgn = ((qbits >> j) ^ (uint32_t)__popc(e & op[32 + j])) & 1u;
+            ar[j] = sgn ? -ar[j] : ar[j];
+            ai[j] = sgn ? -ai[j] : ai[j];
+          }
+          op += SIGNQ_WORDS;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t off = ((j & 1) ? sr[0] : 0u) ^ ((j & 2) ? sr[1] : 0u) ^ ((j & 4) ? sr[2] : 0u) ^ ((j & 8) ? sr[3] : 0u);
+        if (j < nreg) tile[pb ^ off] = make_double2(ar[j], ai[j]);
+      }
+    }
+    __syncthreads();
+    S += nwords;
+  }
+
+  // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order ---------------
+  if (t < ksize) {
+    uint32_t gout = 0;
+    for (int m = 0; m < n - k; ++m) gout |= ((g >> m) & 1u) << P[PW_OUT_GPHYS + m];
+    const uint32_t thr_l = deposit_bits(t, 0, kt, P + PW_OUT_LDS);
+    const uint32_t thr_p = (t & ((1u << lo_out) - 1u)) | deposit_bits(t, lo_out, kt, P + PW_OUT_PHYS);
+    const bool fin = flags & PASS_FINAL;
+    double2* __restrict__ dst = out + b * state_stride + gout;
+    double* __restrict__ pdst = probs + (b << n) + gout;
+#pragma unroll 4
+    for (int i = 0; i < niter; ++i) {
+      uint32_t it_l = 0, it_p = 0;
+      for (int j = kt; j < k; ++j) {
+        const uint32_t bit = ((uint32_t)i >> (j - kt)) & 1u;
+        it_l |= bit << P[PW_OUT_LDS + j];
+        it_p |= bit << P[PW_OUT_PHYS + j];
+      }
+      const double2 v = tile[swz(thr_l | it_l)];
+      if (fin) pdst[thr_p | it_p] = v.x * v.x + v.y * v.y;
+      else dst[thr_p | it_p] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// un-fused kernels: one gate = one HBM round trip (32 * 2^n bytes per state); flat index over
+// [batch * 2^n], physical bit of wire w is n-1-w so pairs never straddle two states.
+// ------------------------------------------------------------------------------------------------
+struct Mat2 { double m[8]; };
+
+__global__ __launch_bounds__(256) void gate1q_kernel(double2* __restrict__ state, long long npairs, int pbit, Mat2 U) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long lowmask = (1ll << pbit) - 1;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < npairs; idx += stride) {
+    const long long i0 = ((idx & ~lowmask) << 1) | (idx & lowmask);
+    const long long i1 = i0 | (1ll << pbit);
+    const double2 x0 = state[i0], x1 = state[i1];
+    double2 y0, y1;
+    y0.x = U.m[0] * x0.x - U.m[1] * x0.y + U.m[2] * x1.x - U.m[3] * x1.y;
+    y0.y = U.m[0] * x0.y + U.m[1] * x0.x + U.m[2] * x1.y + U.m[3] * x1.x;
+    y1.x = U.m[4] * x0.x - U.m[5] * x0.y + U.m[6] * x1.x - U.m[7] * x1.y;
+    y1.y = U.m[4] * x0.y + U.m[5] * x0.x + U.m[6] * x1.y + U.m[7] * x1.x;
+    state[i0] = y0;
+    state[i1] = y1;
+  }
+}
+
+__global__ __launch_bounds__(256) void cnot_kernel(double2* __restrict__ state, long long npairs, int cbit, int tbit) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long lowmask = (1ll << tbit) - 1;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < npairs; idx += stride) {
+    const long long i0 = ((idx & ~lowmask) << 1) | (idx & lowmask);
+    if (!((i0 >> cbit) & 1)) continue;
+    const long long i1 = i0 | (1ll << tbit);
+    const double2 x0 = state[i0], x1 = state[i1];
+    state[i0] = x1;
+    state[i1] = x0;
+  }
+}
+
+__global__ __launch_bounds__(256) void born_probs_kernel(const double2* __restrict__ state, double* __restrict__ probs, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const double2 v = state[i];
+    probs[i] = v.x * v.x + v.y * v.y;
+  }
+}
+
+// grad[p] = scale * sum_z w[z] (q+[z] - q-[z]);  rows (+p, -p) of `shifted`; one workgroup per p.
+// scale = 1/2 (ksd2 == nullptr) or 1/2 / sqrt(max(ksd2, 1e-12)) with the clamp's zero gradient
+// below 1e-12 (ksd_vi_quantum.py:145).  Fixed-order tree reduction: deterministic.
+__global__ __launch_bounds__(256) void shift_dot_kernel(const double* __restrict__ shifted, const double* __restrict__ w,
+                                                        const double* __restrict__ ksd2, long long N,
+                                                        double* __restrict__ grad, double* __restrict__ loss_out) {
+  __shared__ double red[256];
+  const long long p = blockIdx.x;
+  const double* qp = shifted + (2 * p) * N;
+  const double* qm = qp + N;
+  double acc = 0.0;
+  for (long long z = threadIdx.x; z < N; z += blockDim.x) acc += w[z] * (qp[z] - qm[z]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double scale = 0.5;
+    if (ksd2) {
+      const double k2 = *ksd2;
+      const double loss = sqrt(k2 < 1e-12 ? 1e-12 : k2);
+      scale = (k2 < 1e-12) ? 0.0 : 0.5 / loss;
+      if (p == 0 && loss_out) *loss_out = loss;
+    }
+    grad[p] = scale * red[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void dldq_kernel(const double* __restrict__ y, const double* __restrict__ ksd2,
+                                                   long long N, double* __restrict__ dLdq, double* __restrict__ loss_out) {
+  const double k2 = *ksd2;
+  const double loss = sqrt(k2 < 1e-12 ? 1e-12 : k2);
+  const double inv = (k2 < 1e-12) ? 0.0 : 1.0 / loss;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
+    if (dLdq) dLdq[i] = y[i] * inv;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) *loss_out = loss;
+}
+
+// ---- launchers (called from api.hip) --------------------------------------------------------------------
+hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
+                              int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
+                              double* gates, hipStream_t st) {
+  const long long total = (long long)batch * nfused;
+  if (total == 0) return hipSuccess;
+  const int bs = 128;
+  build_gates_kernel<<<dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st>>>(
+      plan, thetas, theta_stride, shift_mode, p_begin, include_base, b_offset, batch, gates);
+  return hipGetLastError();
+}
+
+hipError_t prepare_circuit_kernel(size_t lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, int batch,
+                               const void* in, void* out, double* probs, const double* gates,
+                               long long gate_stride, hipStream_t st) {
+  dim3 grid(1u << (n - k), (unsigned)batch);
+  circuit_pass_kernel<<<grid, dim3(threads), (size_t(1) << k) * 16, st>>>(
+      plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n);
+  return hipGetLastError();
+}
+
+static inline unsigned grid_for(long long work, int bs) {
+  long long g = (work + bs - 1) / bs;
+  if (g > 256 * 8 * 4) g = 256 * 8 * 4;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st) {
+  Mat2 m;
+  for (int i = 0; i < 8; ++i) m.m[i] = U[i];
+  const long long npairs = batch << (n - 1);
+  gate1q_kernel<<<grid_for(npairs, 256), 256, 0, st>>>((double2*)state, npairs, n - 1 - wire, m);
+  return hipGetLastError();
+}
+
+hipError_t launch_cnot(double* state, int n, long long batch, int control, int target, hipStream_t st) {
+  const long long npairs = batch << (n - 1);
+  cnot_kernel<<<grid_for(npairs, 256), 256, 0, st>>>((double2*)state, npairs, n - 1 - control, n - 1 - target);
+  return hipGetLastError();
+}
+
+hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st) {
+  const long long total = batch << n;
+  born_probs_kernel<<<grid_for(total, 256), 256, 0, st>>>((const double2*)state, probs, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_shift_dot(const double* shifted, int n_shift, const double* w, const double* ksd2, int n,
+                            double* grad, double* loss_out, hipStream_t st) {
+  if (n_shift <= 0) return hipSuccess;
+  shift_dot_kernel<<<n_shift, 256, 0, st>>>(shifted, w, ksd2, 1ll << n, grad, loss_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dldq(const double* y, const double* ksd2, int n, double* dLdq, double* loss_out, hipStream_t st) {
+  const long long N = 1ll << n;
+  dldq_kernel<<<grid_for(N, 256), 256, 0, st>>>(y, ksd2, N, dLdq, loss_out);
+  return hipGetLastError();
+}
+
+}  // namespace bornvi

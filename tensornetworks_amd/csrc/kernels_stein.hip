@@ -1,0 +1,359 @@
+// Stein-kernel side of the KSD hot path on gfx950: score function from packed CPTs, dense
+// Gram matrix K_p, the quadratic form q^T K_p q (HBM-bound GEMV) and the pack / combine steps
+// of the matrix-free mat-vec.  All fp64; every reduction has a fixed order (no atomics), so
+// results are bitwise reproducible.
+//
+// Index convention: outcome index i <-> tuple z with z[b] = (i >> (n-1-b)) & 1 (utils.py:77-91).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "kernels.hpp"
+
+namespace bornvi {
+
+// ------------------------------------------------------------------------------------------------
+// score: S[z, b] = 1 - p(x, flip_b z) / p(x, z), zeros when |p(x,z)| < 1e-12
+// (stein_utils.py:115-136 on top of compute_prob_joint_xz :58-112 and
+//  BayesianNetwork.get_joint_probability bayesian_network.py:111-146).  Same operation order as
+// the reference: product over nodes in network order, hidden nodes summed in lexicographic order.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double joint_xz(const bornvi_bn_desc& bn, int n, unsigned long long z, int n_hidden) {
+  double tot = 0.0;
+  const unsigned long long n_assign = 1ull << n_hidden;
+  for (unsigned long long a = 0; a < n_assign; ++a) {
+    unsigned long long vals = 0;  // bit v = value of node v
+    int h = 0;
+    for (int v = 0; v < bn.num_nodes; ++v) {
+      const int role = bn.role[v];
+      unsigned long long bit;
+      if (role >= 0) bit = (z >> (n - 1 - role)) & 1ull;
+      else if (role == -1) bit = 0ull;
+      else if (role == -2) bit = 1ull;
+      else { bit = (a >> (n_hidden - 1 - h)) & 1ull; ++h; }
+      vals |= bit << v;
+    }
+    double prob = 1.0;
+    for (int v = 0; v < bn.num_nodes; ++v) {
+      int cfg = 0;
+      const int np = bn.n_parents[v];
+      for (int p = 0; p < np; ++p) cfg = cfg * 2 + (int)((vals >> bn.parents[v * bn.max_parents + p]) & 1ull);
+      prob *= bn.cpt[bn.cpt_off[v] + 2 * cfg + (int)((vals >> v) & 1ull)];
+    }
+    tot += prob;
+  }
+  return tot;
+}
+
+__global__ __launch_bounds__(256) void score_kernel(bornvi_bn_desc bn, int n, double* __restrict__ S, double* __restrict__ pxz) {
+  const unsigned long long N = 1ull << n;
+  const unsigned long long z = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (z >= N) return;
+  int n_hidden = 0;
+  for (int v = 0; v < bn.num_nodes; ++v) n_hidden += (bn.role[v] == -3);
+  const double p = joint_xz(bn, n, z, n_hidden);
+  if (pxz) pxz[z] = p;
+  const bool degenerate = fabs(p) < 1e-12;
+  for (int b = 0; b < n; ++b) {
+    double s = 0.0;
+    if (!degenerate) {
+      const double pf = joint_xz(bn, n, z ^ (1ull << (n - 1 - b)), n_hidden);
+      s = 1.0 - (pf / p);
+    }
+    S[z * n + b] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense Gram.  Closed form of stein_utils.get_stein_kernel_kp_value (:138-197) with the Hamming
+// base kernel (:30-55), a = exp(-1/(n l)), d = popcount(i ^ j), T = S - 1:
+//   k_p(i,j) = a^d [ sum_b S_ib S_jb - c_same sum_b (T_ib + T_jb) - (c_diff - c_same) sum_{b: i_b != j_b} (T_ib + T_jb) ]
+//   c_same = 1 - a, c_diff = 1 - 1/a.
+// Every term is evaluated symmetrically in (i, j), so K is bitwise symmetric.
+// Thread = two adjacent columns (16-byte stores), workgroup = 512 columns x GRAM_ROWS rows; the
+// row-side quantities are wave-uniform.  HBM-write bound (8 * 4^n bytes).
+// ------------------------------------------------------------------------------------------------
+constexpr int GRAM_ROWS = 64;
+struct PowTable { double v[33]; };
+
+template <int NB>
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ S, double* __restrict__ K,
+                                                   PowTable apow, double c_same, double dc) {
+  const long long N = 1ll << NB;
+  const long long j0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (j0 >= N) return;
+  double Sj[2][NB], Tj[2][NB], RTj[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    RTj[c] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      Sj[c][b] = S[(j0 + c) * NB + b];
+      Tj[c][b] = Sj[c][b] - 1.0;
+      RTj[c] += Tj[c][b];
+    }
+  }
+  const long long i_begin = (long long)blockIdx.y * GRAM_ROWS;
+  const long long i_end = (i_begin + GRAM_ROWS < N) ? i_begin + GRAM_ROWS : N;
+  for (long long i = i_begin; i < i_end; ++i) {
+    double Si[NB], Ti[NB], RTi = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { Si[b] = S[i * NB + b]; Ti[b] = Si[b] - 1.0; RTi += Ti[b]; }
+    double out[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned x = (unsigned)(i ^ (j0 + c));
+      double dot = 0.0, ms = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        dot = fma(Si[b], Sj[c][b], dot);
+        const double v = Ti[b] + Tj[c][b];
+        ms += ((x >> (NB - 1 - b)) & 1u) ? v : 0.0;
+      }
+      out[c] = apow.v[__popc(x)] * (dot - c_same * (RTi + RTj[c]) - dc * ms);
+    }
+    *reinterpret_cast<double2*>(K + i * N + j0) = make_double2(out[0], out[1]);
+  }
+}
+
+template <int NB>
+static hipError_t launch_gram_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc, hipStream_t st) {
+  const long long N = 1ll << NB;
+  dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)((N + GRAM_ROWS - 1) / GRAM_ROWS));
+  gram_kernel<NB><<<grid, 256, 0, st>>>(S, K, apow, c_same, dc);
+  return hipGetLastError();
+}
+
+hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, hipStream_t st) {
+  PowTable apow;
+  const double denom = (double)n * length_scale;
+  for (int d = 0; d <= 32; ++d) apow.v[d] = std::exp(-(double)d / denom);  // stein_utils.py:55
+  const double a = apow.v[1];
+  const double c_same = 1.0 - a, c_diff = 1.0 - 1.0 / a;
+  const double dc = c_diff - c_same;
+  switch (n) {
+#define BORNVI_GRAM_CASE(NB) case NB: return launch_gram_nb<NB>(S, K, apow, c_same, dc, st);
+    BORNVI_GRAM_CASE(1) BORNVI_GRAM_CASE(2) BORNVI_GRAM_CASE(3) BORNVI_GRAM_CASE(4) BORNVI_GRAM_CASE(5)
+    BORNVI_GRAM_CASE(6) BORNVI_GRAM_CASE(7) BORNVI_GRAM_CASE(8) BORNVI_GRAM_CASE(9) BORNVI_GRAM_CASE(10)
+    BORNVI_GRAM_CASE(11) BORNVI_GRAM_CASE(12) BORNVI_GRAM_CASE(13) BORNVI_GRAM_CASE(14) BORNVI_GRAM_CASE(15)
+    BORNVI_GRAM_CASE(16) BORNVI_GRAM_CASE(17)
+#undef BORNVI_GRAM_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// k_p for M explicit pairs (the batched form of one get_stein_kernel_kp_value call, stein_utils.py:138-197):
+// zi/zj outcome indices, si/sj [M, n] score rows supplied by the caller.  Same closed form as gram_kernel.
+__global__ __launch_bounds__(256) void kp_pairs_kernel(int n, PowTable apow, double c_same, double dc, long long M,
+                                                       const long long* __restrict__ zi, const long long* __restrict__ zj,
+                                                       const double* __restrict__ si, const double* __restrict__ sj,
+                                                       double* __restrict__ out) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const unsigned x = (unsigned)(zi[m] ^ zj[m]);
+  double dot = 0.0, ms = 0.0, rti = 0.0, rtj = 0.0;
+  for (int b = 0; b < n; ++b) {
+    const double a_ = si[m * n + b], b_ = sj[m * n + b];
+    const double ta = a_ - 1.0, tb = b_ - 1.0;
+    dot = fma(a_, b_, dot);
+    rti += ta; rtj += tb;
+    ms += ((x >> (n - 1 - b)) & 1u) ? (ta + tb) : 0.0;
+  }
+  out[m] = apow.v[__popc(x)] * (dot - c_same * (rti + rtj) - dc * ms);
+}
+
+hipError_t launch_kp_pairs(int n, double length_scale, long long M, const long long* zi, const long long* zj,
+                           const double* si, const double* sj, double* out, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  PowTable apow;
+  const double denom = (double)n * length_scale;
+  for (int d = 0; d <= 32; ++d) apow.v[d] = std::exp(-(double)d / denom);
+  const double a = apow.v[1];
+  const double c_same = 1.0 - a, c_diff = 1.0 - 1.0 / a;
+  kp_pairs_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(n, apow, c_same, c_diff - c_same, M, zi, zj, si, sj, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// quadratic form: y = K q (row-major K, one pass over 8 * 4^n bytes), ksd2 = q . y.
+// One wave owns QF_ROWS consecutive rows and streams them with 16-byte non-temporal loads; q stays
+// in L2.  Wave reduction by xor-shuffles, then per-workgroup partials, then one summing kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int QF_ROWS = 4;
+constexpr int QF_WAVES = 4;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64 * QF_WAVES) void quadform_kernel(const double* __restrict__ K, const double* __restrict__ q,
+                                                                 double* __restrict__ y, double* __restrict__ partials, long long N) {
+  __shared__ double wpart[QF_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long row0 = ((long long)blockIdx.x * QF_WAVES + wave) * QF_ROWS;
+  double acc[QF_ROWS];
+#pragma unroll
+  for (int r = 0; r < QF_ROWS; ++r) acc[r] = 0.0;
+  if (row0 < N) {
+    const double* __restrict__ Kr = K + row0 * N;
+    if (row0 + QF_ROWS <= N) {
+#pragma unroll 4
+      for (long long c = lane * 2; c < N; c += 128) {
+        const double2 q2 = *reinterpret_cast<const double2*>(q + c);
+#pragma unroll
+        for (int r = 0; r < QF_ROWS; ++r) {
+          const double* p = Kr + r * N + c;
+          const double kx = __builtin_nontemporal_load(p), ky = __builtin_nontemporal_load(p + 1);
+          acc[r] = fma(kx, q2.x, fma(ky, q2.y, acc[r]));
+        }
+      }
+    } else {
+      for (long long c = lane * 2; c < N; c += 128) {
+        const double2 q2 = *reinterpret_cast<const double2*>(q + c);
+        for (int r = 0; r < QF_ROWS; ++r)
+          if (row0 + r < N) {
+            const double* p = Kr + r * N + c;
+            acc[r] = fma(p[0], q2.x, fma(p[1], q2.y, acc[r]));
+          }
+      }
+    }
+  }
+  double part = 0.0;
+#pragma unroll
+  for (int r = 0; r < QF_ROWS; ++r) {
+    acc[r] = wave_sum(acc[r]);
+    if (row0 + r < N) {
+      if (lane == 0 && y) y[row0 + r] = acc[r];
+      part += q[row0 + r] * acc[r];
+    }
+  }
+  if (lane == 0) wpart[wave] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < QF_WAVES; ++w) s += wpart[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, long long count, double* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (long long i = threadIdx.x; i < count; i += 256) acc += partials[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+size_t quadform_partials(int n) {
+  const long long N = 1ll << n;
+  return (size_t)((N + QF_ROWS * QF_WAVES - 1) / (QF_ROWS * QF_WAVES));
+}
+
+hipError_t launch_quadform(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
+                           double* partials, double* /*ytmp*/, hipStream_t st) {
+  const long long N = 1ll << n;
+  const size_t nwg = quadform_partials(n);
+  quadform_kernel<<<(unsigned)nwg, 64 * QF_WAVES, 0, st>>>(K, q, y_or_null, partials, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  sum_partials_kernel<<<1, 256, 0, st>>>(partials, (long long)nwg, ksd2);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// matrix-free y = K_p q.  The n+1 real vectors v_0 = q, v_{b+1} = s_b o q
+// are packed two per complex128 state, pushed through K_base = M^{(x) n} by the circuit pass engine
+// (real 2x2 butterflies act on re and im independently), then combined:
+//   y = sum_b [ s_b o w_b - s_b o (u - flip_b u) - (w_b - flip_b w_b) + 2 (u - flip_b u) ],
+//   u = K_base q, w_b = K_base (s_b o q).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kron_pack_kernel(int n, const double* __restrict__ S, const double* __restrict__ q,
+                                                        double2* __restrict__ packed, double a, double* __restrict__ gate) {
+  const long long N = 1ll << n;
+  const int npk = (n + 2) / 2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    gate[0] = 1.0; gate[1] = 0.0; gate[2] = a; gate[3] = 0.0;
+    gate[4] = a; gate[5] = 0.0; gate[6] = 1.0; gate[7] = 0.0;
+  }
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const double qi = q[i];
+    for (int c = 0; c < npk; ++c) {
+      const int v0 = 2 * c, v1 = 2 * c + 1;
+      const double re = (v0 == 0) ? qi : S[i * n + (v0 - 1)] * qi;
+      const double im = (v1 <= n) ? S[i * n + (v1 - 1)] * qi : 0.0;
+      packed[c * N + i] = make_double2(re, im);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kron_combine_kernel(int n, const double* __restrict__ S, const double* __restrict__ q,
+                                                           const double* __restrict__ packed, double* __restrict__ y,
+                                                           double* __restrict__ partials) {
+  __shared__ double red[256];
+  const long long N = 1ll << n;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  double part = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    const double ui = packed[i * 2];
+    double acc = 0.0;
+    for (int b = 0; b < n; ++b) {
+      const long long f = i ^ (1ll << (n - 1 - b));
+      const int v = b + 1;
+      const double* wv = packed + ((long long)(v >> 1) * N) * 2 + (v & 1);
+      const double wi = wv[i * 2], wf = wv[f * 2];
+      const double du = ui - packed[f * 2];
+      const double sb = S[i * n + b];
+      acc += sb * wi - sb * du - (wi - wf) + 2.0 * du;
+    }
+    if (y) y[i] = acc;
+    part += q[i] * acc;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+size_t kron_partials(int n) {
+  const long long N = 1ll << n;
+  long long g = (N + 255) / 256;
+  if (g > 2048) g = 2048;
+  return (size_t)g;
+}
+
+hipError_t launch_kron_pack(int n, double length_scale, const double* S, const double* q, double* packed,
+                            double* gate, hipStream_t st) {
+  const double a = std::exp(-1.0 / ((double)n * length_scale));
+  kron_pack_kernel<<<(unsigned)kron_partials(n), 256, 0, st>>>(n, S, q, (double2*)packed, a, gate);
+  return hipGetLastError();
+}
+
+hipError_t launch_kron_combine(int n, const double* S, const double* q, const double* packed, double* y,
+                               double* partials, double* ksd2, hipStream_t st) {
+  const size_t g = kron_partials(n);
+  kron_combine_kernel<<<(unsigned)g, 256, 0, st>>>(n, S, q, packed, y, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  sum_partials_kernel<<<1, 256, 0, st>>>(partials, (long long)g, ksd2);
+  return hipGetLastError();
+}
+
+hipError_t launch_score(const bornvi_bn_desc& bn, int n, double* S, double* pxz, hipStream_t st) {
+  const long long N = 1ll << n;
+  score_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(bn, n, S, pxz);
+  return hipGetLastError();
+}
+
+}  // namespace bornvi

@@ -1,0 +1,408 @@
+// Circuit execution planner -- see plan.hpp for the model.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+
+namespace bornvi {
+
+int num_params(int ansatz, int n, int layers) {
+  // quantum_born_machine.py:31-38
+  if (ansatz == 0 || ansatz == 1) return layers * 3 * n;
+  if (ansatz == 2) return layers * 2 * n;
+  return -1;
+}
+
+bool build_gate_list(int ansatz, int n, int layers, std::vector<Gate>& g) {
+  g.clear();
+  int p = 0;
+  auto rot = [&](int kind, int w) { g.push_back({kind, w, -1, p++}); };
+  if (ansatz == 0) {  // hardware_efficient, quantum_born_machine.py:58-87
+    for (int i = 0; i < n; ++i) g.push_back({G_H, i, -1, -1});
+    for (int l = 0; l < layers; ++l) {
+      for (int i = 0; i < n; ++i) { rot(G_RX, i); rot(G_RY, i); rot(G_RZ, i); }
+      if (n > 1) {
+        for (int i = 0; i + 1 < n; ++i) g.push_back({G_CNOT, i, i + 1, -1});
+        if (n > 2) g.push_back({G_CNOT, n - 1, 0, -1});
+        if (l % 2 == 0 && n > 2)
+          for (int i = 0; i < n - 2; i += 2) g.push_back({G_CZ, i, i + 2, -1});
+      }
+    }
+  } else if (ansatz == 1) {  // all_to_all, quantum_born_machine.py:90-111
+    for (int i = 0; i < n; ++i) g.push_back({G_H, i, -1, -1});
+    for (int l = 0; l < layers; ++l) {
+      for (int i = 0; i < n; ++i) { rot(G_RX, i); rot(G_RY, i); rot(G_RZ, i); }
+      if (n > 1)
+        for (int i = 0; i < n; ++i)
+          for (int j = i + 1; j < n; ++j) g.push_back({G_CZ, i, j, -1});
+    }
+  } else if (ansatz == 2) {  // basic, quantum_born_machine.py:114-128
+    for (int l = 0; l < layers; ++l) {
+      for (int i = 0; i < n; ++i) { rot(G_RY, i); rot(G_RZ, i); }
+      if (n > 1) {
+        for (int i = 0; i + 1 < n; ++i) g.push_back({G_CNOT, i, i + 1, -1});
+        if (n > 2) g.push_back({G_CNOT, n - 1, 0, -1});
+      }
+    }
+  } else {
+    return false;
+  }
+  return true;
+}
+
+namespace {
+
+enum { K_U1 = 0, K_CX = 1, K_CZ = 2 };
+struct Op { int kind, a, b, idx; };  // U1: a = wire, idx = fused gate; CX: a = control, b = target; CZ: a, b
+using Fused = std::array<uint32_t, FUSED_WORDS>;
+
+void fuse_gates(const std::vector<Gate>& gates, int n, std::vector<Op>& ops, std::vector<Fused>& fused) {
+  std::vector<int> open(n, -1);
+  for (const Gate& g : gates) {
+    if (g.kind <= G_RZ) {
+      int f = open[g.w0];
+      if (f < 0 || fused[f][1] >= (uint32_t)FUSED_MAX_ELEMS) {
+        Fused nf; nf.fill(0xffffffffu);
+        nf[0] = (uint32_t)g.w0; nf[1] = 0;
+        fused.push_back(nf);
+        f = (int)fused.size() - 1;
+        open[g.w0] = f;
+        ops.push_back({K_U1, g.w0, -1, f});
+      }
+      uint32_t e = fused[f][1]++;
+      fused[f][2 + 2 * e] = (uint32_t)g.kind;
+      fused[f][3 + 2 * e] = (uint32_t)g.param;  // -1 -> 0xffffffff
+    } else {
+      open[g.w0] = open[g.w1] = -1;
+      ops.push_back({g.kind == G_CNOT ? K_CX : K_CZ, g.w0, g.w1, -1});
+    }
+  }
+}
+
+inline int op_target(const Op& o) { return o.kind == K_U1 ? o.a : (o.kind == K_CX ? o.b : -1); }
+
+// Greedy selection in program order: an op runs if none of its wires is blocked and its
+// non-diagonal target is (or can become) one of at most `cap` "near" wires.  Anything that
+// cannot run blocks its wires for the rest of the scan (ops on disjoint wires commute).
+void greedy_select(const std::vector<Op>& ops, const std::vector<int>& pool, int n, int cap,
+                   std::vector<int>& sel, std::vector<int>& rest, std::vector<int>& targets) {
+  std::vector<char> blocked(n, 0), in_t(n, 0);
+  sel.clear(); rest.clear(); targets.clear();
+  for (int idx : pool) {
+    const Op& o = ops[idx];
+    bool blk = blocked[o.a] || (o.b >= 0 && blocked[o.b]);
+    int t = op_target(o);
+    if (!blk && t >= 0 && !in_t[t]) {
+      if ((int)targets.size() < cap) { in_t[t] = 1; targets.push_back(t); }
+      else blk = true;
+    }
+    if (blk) {
+      blocked[o.a] = 1;
+      if (o.b >= 0) blocked[o.b] = 1;
+      rest.push_back(idx);
+    } else {
+      sel.push_back(idx);
+    }
+  }
+}
+
+// Order LDS bit positions so that consecutive lanes are bank-conflict free under the
+// XOR-fold swizzle (phys low nibble = xor of all nibbles of the index): lane bits 0..2 go to
+// positions with residues {0,1,2} mod 4, lane bit 3 to residue 3, lane bit 4 to the residue of
+// lane bit 0 or 1 (ds_read_b128 services lanes {0-3,12-15,20-27} together).
+std::vector<int> order_for_banks(std::vector<int> pos) {
+  std::sort(pos.begin(), pos.end());
+  std::vector<int> out;
+  std::vector<char> used(pos.size(), 0);
+  bool res_used[4] = {false, false, false, false};
+  auto take = [&](auto pred) -> bool {
+    for (size_t i = 0; i < pos.size(); ++i)
+      if (!used[i] && pred(pos[i])) { used[i] = 1; out.push_back(pos[i]); res_used[pos[i] & 3] = true; return true; }
+    return false;
+  };
+  for (int s = 0; s < 3 && out.size() < pos.size(); ++s)
+    if (!take([&](int p) { return (p & 3) != 3 && !res_used[p & 3]; }))
+      take([&](int) { return true; });
+  if (out.size() < pos.size())
+    if (!take([&](int p) { return (p & 3) == 3; })) take([&](int) { return true; });
+  if (out.size() < pos.size() && out.size() >= 2) {
+    int r0 = out[0] & 3, r1 = out[1] & 3;
+    if (!take([&](int p) { return (p & 3) == r0 || (p & 3) == r1; })) take([&](int) { return true; });
+  }
+  for (size_t i = 0; i < pos.size(); ++i)
+    if (!used[i]) out.push_back(pos[i]);
+  return out;
+}
+
+struct PassInfo {
+  std::vector<int> ops;      // op indices, program order
+  std::vector<int> targets;  // wires that must be local
+  std::vector<int> local;    // k wires
+  std::vector<int> global;   // n-k wires, workgroup-index bit m <-> global[m]
+  std::vector<int> lds_wire; // wire at LDS bit j
+  std::vector<int> in_low;   // A_i (phys-in bits 0..lo_in-1)
+  std::vector<int> out_low;  // B_i
+};
+
+}  // namespace
+
+namespace {
+struct BuildSpec {
+  int n = 0;
+  std::vector<Op> ops;
+  std::vector<Fused> fused;
+  int n_params = 0, n_gates = 0;
+  bool in_state = false;   // first pass loads a canonical-order state instead of |0...0>
+  bool out_state = false;  // last pass writes the canonical-order state instead of |psi|^2
+};
+bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::string& msg);
+}  // namespace
+
+bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& plan, std::string& msg) {
+  if (n < 1 || n > 30) { msg = "num qubits must be in [1, 30]"; return false; }
+  if (layers < 0) { msg = "layers must be >= 0"; return false; }
+  std::vector<Gate> gates;
+  if (!build_gate_list(ansatz, n, layers, gates)) { msg = "unknown ansatz id"; return false; }
+  BuildSpec spec;
+  spec.n = n;
+  fuse_gates(gates, n, spec.ops, spec.fused);
+  spec.n_params = num_params(ansatz, n, layers);
+  spec.n_gates = (int)gates.size();
+  return build_plan(spec, opt, plan, msg);
+}
+
+// v -> (M (x) M (x) ... (x) M) v for one shared 2x2 matrix (fused gate 0): state in, state out.
+// Wires are visited from the least significant physical bit upwards so that the first and the
+// last pass both hold the canonical low bits locally.
+bool make_kron_plan(int n, const PlanOptions& opt, Plan& plan, std::string& msg) {
+  if (n < 1 || n > 30) { msg = "num bits must be in [1, 30]"; return false; }
+  BuildSpec spec;
+  spec.n = n;
+  Fused f; f.fill(0xffffffffu); f[0] = 0; f[1] = 0;
+  spec.fused.push_back(f);
+  for (int w = n - 1; w >= 0; --w) spec.ops.push_back({K_U1, w, -1, 0});
+  spec.in_state = spec.out_state = true;
+  spec.n_gates = n;
+  return build_plan(spec, opt, plan, msg);
+}
+
+namespace {
+bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::string& msg) {
+  const int n = spec.n;
+  const std::vector<Op>& ops = spec.ops;
+  const std::vector<Fused>& fused = spec.fused;
+  const int k = std::min(n, opt.kmax);
+  const int r = std::min(opt.r, k);
+  if (r > 4) { msg = "at most 4 register wires"; return false; }
+  int threads = 64;
+  while (threads < (1 << (k - r))) threads <<= 1;
+  if (threads > opt.max_threads) { msg = "tile needs more threads than allowed"; return false; }
+  if (fused.size() > 65535) { msg = "too many fused gates"; return false; }
+
+  // ---- passes -------------------------------------------------------------------------------
+  std::vector<PassInfo> passes;
+  {
+    std::vector<int> pool(ops.size());
+    for (size_t i = 0; i < ops.size(); ++i) pool[i] = (int)i;
+    std::vector<int> sel, rest, tg;
+    while (!pool.empty()) {
+      greedy_select(ops, pool, n, k, sel, rest, tg);
+      if (sel.empty()) { msg = "planner made no progress"; return false; }
+      PassInfo pi; pi.ops = sel; pi.targets = tg;
+      passes.push_back(pi);
+      pool = rest;
+    }
+    if (passes.empty()) passes.push_back(PassInfo{});
+  }
+  const int lo_can = std::min(opt.lo, k);
+  std::vector<int> canon_low;  // wire at canonical physical bit p is n-1-p
+  for (int p = 0; p < lo_can; ++p) canon_low.push_back(n - 1 - p);
+  {
+    std::vector<char> in(n, 0);
+    int cnt = 0;
+    for (int w : passes.back().targets) { in[w] = 1; ++cnt; }
+    for (int w : canon_low) if (!in[w]) { in[w] = 1; ++cnt; }
+    if (cnt > k) passes.push_back(PassInfo{});  // pure re-layout pass
+  }
+  if (spec.in_state) {
+    std::vector<char> in(n, 0);
+    int cnt = 0;
+    for (int w : passes.front().targets) { in[w] = 1; ++cnt; }
+    for (int w : canon_low) if (!in[w]) { in[w] = 1; ++cnt; }
+    if (cnt > k) passes.insert(passes.begin(), PassInfo{});  // pure re-layout pass in front
+  }
+  const int np = (int)passes.size();
+  // local sets: targets, then padding that favours overlap with the neighbours
+  for (int i = 0; i < np; ++i) {
+    PassInfo& P = passes[i];
+    std::vector<char> in(n, 0);
+    auto add = [&](int w) { if (!in[w] && (int)P.local.size() < k) { in[w] = 1; P.local.push_back(w); } };
+    for (int w : P.targets) add(w);
+    if (i == np - 1) for (int w : canon_low) add(w);
+    if (i == 0 && spec.in_state) for (int w : canon_low) add(w);
+    if (i + 1 < np) for (int w : passes[i + 1].targets) add(w);
+    if (i > 0) for (int w : passes[i - 1].local) add(w);
+    for (int w = n - 1; w >= 0; --w) add(w);
+    for (int w = 0; w < n; ++w) if (!in[w]) P.global.push_back(w);
+  }
+  // Sequentially: LDS bit assignment of pass i (in_low wires first -- identity with the low
+  // phys-in bits -- then the rest ascending), then out_low(i) = in_low(i+1), a subset of
+  // local(i) & local(i+1) ordered for conflict-free LDS reads in the store phase.
+  if (spec.in_state) passes[0].in_low = canon_low;
+  for (int i = 0; i < np; ++i) {
+    PassInfo& P = passes[i];
+    std::vector<char> placed(n, 0);
+    for (int w : P.in_low) { P.lds_wire.push_back(w); placed[w] = 1; }
+    std::vector<int> others;
+    for (int w : P.local) if (!placed[w]) others.push_back(w);
+    std::sort(others.begin(), others.end());
+    for (int w : others) P.lds_wire.push_back(w);
+    if (i == np - 1) { P.out_low = canon_low; break; }
+    std::vector<char> nxt(n, 0);
+    for (int w : passes[i + 1].local) nxt[w] = 1;
+    std::vector<int> ldspos(n, -1);
+    for (int j = 0; j < k; ++j) ldspos[P.lds_wire[j]] = j;
+    std::vector<int> pos;
+    for (int w : P.local) if (nxt[w]) pos.push_back(ldspos[w]);
+    pos = order_for_banks(pos);
+    const int lo = std::min((int)pos.size(), std::min(opt.lo, k));
+    for (int j = 0; j < lo; ++j) P.out_low.push_back(P.lds_wire[pos[j]]);
+    passes[i + 1].in_low = P.out_low;
+  }
+  // physical layout of the buffer written by pass i: out_low wires at bits 0.., the rest ascending;
+  // the last pass writes the canonical order (wire w at bit n-1-w).
+  std::vector<std::vector<int>> layout(np, std::vector<int>(n, -1));  // layout[i][wire] = phys bit
+  for (int i = 0; i < np; ++i) {
+    if (i == np - 1) { for (int w = 0; w < n; ++w) layout[i][w] = n - 1 - w; continue; }
+    int p = 0;
+    for (int w : passes[i].out_low) layout[i][w] = p++;
+    for (int w = 0; w < n; ++w) if (layout[i][w] < 0) layout[i][w] = p++;
+  }
+
+  // ---- serialise ------------------------------------------------------------------------------
+  std::vector<uint32_t>& W = plan.words;
+  W.assign(PH_SIZE, 0);
+  W[PH_MAGIC] = PLAN_MAGIC; W[PH_N] = n; W[PH_K] = k; W[PH_NPASSES] = np;
+  W[PH_NFUSED] = (uint32_t)fused.size(); W[PH_NPARAMS] = (uint32_t)spec.n_params;
+  W[PH_THREADS] = threads; W[PH_R] = r; W[PH_NGATES] = (uint32_t)spec.n_gates;
+  W[PH_OFF_FUSED] = (uint32_t)W.size();
+  for (const Fused& f : fused) W.insert(W.end(), f.begin(), f.end());
+  W[PH_OFF_PASSTAB] = (uint32_t)W.size();
+  W.resize(W.size() + np, 0);
+  plan.pass_off.assign(np, 0);
+
+  for (int i = 0; i < np; ++i) {
+    const PassInfo& P = passes[i];
+    const uint32_t base = (uint32_t)W.size();
+    plan.pass_off[i] = base;
+    W[W[PH_OFF_PASSTAB] + i] = base;
+    W.resize(base + PW_STAGES, 0);
+    uint32_t flags = 0;
+    if (i == 0 && !spec.in_state) flags |= PASS_INIT;
+    if (i == np - 1) flags |= spec.out_state ? PASS_FINAL_STATE : PASS_FINAL;
+    std::vector<int> ldspos(n, -1), gpos(n, -1);
+    for (int j = 0; j < k; ++j) ldspos[P.lds_wire[j]] = j;
+    for (int m = 0; m < n - k; ++m) gpos[P.global[m]] = m;
+    auto extpos = [&](int w) { return ldspos[w] >= 0 ? ldspos[w] : k + gpos[w]; };
+    const int lo_in = (int)P.in_low.size(), lo_out = (int)P.out_low.size();
+    W[base + PW_FLAGS] = flags; W[base + PW_K] = k; W[base + PW_N] = n;
+    W[base + PW_LO_IN] = lo_in; W[base + PW_LO_OUT] = lo_out; W[base + PW_THREADS] = threads;
+    for (int j = 0; j < k; ++j) {
+      W[base + PW_WIRE_OF_LDS + j] = P.lds_wire[j];
+      W[base + PW_IN_PHYS + j] = (i > 0) ? layout[i - 1][P.lds_wire[j]] : (n - 1 - P.lds_wire[j]);
+    }
+    for (int m = 0; m < n - k; ++m) {
+      W[base + PW_WIRE_OF_G + m] = P.global[m];
+      W[base + PW_IN_GPHYS + m] = (i > 0) ? layout[i - 1][P.global[m]] : (n - 1 - P.global[m]);
+      W[base + PW_OUT_GPHYS + m] = layout[i][P.global[m]];
+    }
+    {  // out enumeration: out_low wires first (phys bit j), then the other local wires by LDS position
+      std::vector<char> isl(n, 0);
+      int j = 0;
+      for (int w : P.out_low) { W[base + PW_OUT_LDS + j] = ldspos[w]; W[base + PW_OUT_PHYS + j] = layout[i][w]; isl[w] = 1; ++j; }
+      for (int q = 0; q < k; ++q) {
+        int w = P.lds_wire[q];
+        if (isl[w]) continue;
+        W[base + PW_OUT_LDS + j] = q; W[base + PW_OUT_PHYS + j] = layout[i][w]; ++j;
+      }
+    }
+    // ---- stages ----
+    std::vector<int> pool = P.ops, sel, rest, tg;
+    uint32_t nstages = 0;
+    while (!pool.empty()) {
+      greedy_select(ops, pool, n, r, sel, rest, tg);
+      if (sel.empty()) { msg = "stage planner made no progress"; return false; }
+      // register wires: targets, padded with local wires (highest LDS bits first: they cost nothing
+      // for coalescing and keep the low bits for the lanes)
+      std::vector<char> isr(n, 0);
+      std::vector<int> regw = tg;
+      for (int w : regw) isr[w] = 1;
+      for (int j = k - 1; j >= 0 && (int)regw.size() < r; --j)
+        if (!isr[P.lds_wire[j]]) { isr[P.lds_wire[j]] = 1; regw.push_back(P.lds_wire[j]); }
+      std::vector<int> regbit(n, -1);
+      uint32_t rho = 0;
+      for (int b = 0; b < r; ++b) { regbit[regw[b]] = b; rho |= (uint32_t)ldspos[regw[b]] << (8 * b); }
+      std::vector<int> freepos;
+      for (int j = 0; j < k; ++j) if (!isr[P.lds_wire[j]]) freepos.push_back(j);
+      freepos = order_for_banks(freepos);
+      uint32_t tpos[4] = {0, 0, 0, 0};
+      for (size_t j = 0; j < freepos.size() && j < 16; ++j) tpos[j / 4] |= (uint32_t)freepos[j] << (8 * (j % 4));
+
+      const uint32_t sbase = (uint32_t)W.size();
+      W.resize(sbase + STAGE_HDR_WORDS, 0);
+      W[sbase + 1] = rho;
+      for (int q = 0; q < 4; ++q) W[sbase + 2 + q] = tpos[q];
+      uint32_t nops = 0;
+      for (size_t s = 0; s < sel.size();) {
+        const Op& o = ops[sel[s]];
+        if (o.kind == K_U1) {
+          W.push_back(OP_U1 | ((uint32_t)regbit[o.a] << 4) | ((uint32_t)o.idx << 16));
+          ++nops; ++s;
+        } else if (o.kind == K_CX) {
+          if (regbit[o.a] >= 0) W.push_back(OP_CX_RR | ((uint32_t)regbit[o.a] << 4) | ((uint32_t)regbit[o.b] << 10));
+          else W.push_back(OP_CX_AR | ((uint32_t)extpos(o.a) << 4) | ((uint32_t)regbit[o.b] << 10));
+          ++nops; ++s;
+        } else {  // a run of CZ gates -> one sign quadratic form over the extended index
+          uint32_t U[32]; std::memset(U, 0, sizeof(U));
+          uint32_t Sym[32]; std::memset(Sym, 0, sizeof(Sym));
+          while (s < sel.size() && ops[sel[s]].kind == K_CZ) {
+            int ea = extpos(ops[sel[s]].a), eb = extpos(ops[sel[s]].b);
+            int lo2 = std::min(ea, eb), hi2 = std::max(ea, eb);
+            U[lo2] ^= 1u << hi2;               // CZ twice = identity, hence xor
+            Sym[lo2] ^= 1u << hi2; Sym[hi2] ^= 1u << lo2;
+            ++s;
+          }
+          W.push_back(OP_SIGNQ);
+          for (int a = 0; a < 32; ++a) W.push_back(U[a]);
+          uint32_t qbits = 0;
+          for (int j = 0; j < 16; ++j) {
+            uint32_t off = 0, m = 0;
+            for (int b = 0; b < r; ++b) if (j >> b & 1) { off |= 1u << ldspos[regw[b]]; m ^= Sym[ldspos[regw[b]]]; }
+            uint32_t qv = 0;
+            for (int a = 0; a < 32; ++a) if (off >> a & 1) qv ^= (uint32_t)__builtin_popcount(off & U[a]) & 1u;
+            if (j >= (1 << r)) { m = 0; qv = 0; }
+            W.push_back(m);
+            qbits |= qv << j;
+          }
+          W.push_back(qbits);
+          ++nops;
+        }
+      }
+      // word 0: r | nops << 8 | (words in this stage) << 16, so the kernel can step to the next one
+      const uint32_t nwords = (uint32_t)W.size() - sbase;
+      if (nwords >= (1u << 16) || nops >= 256) { msg = "stage too large"; return false; }
+      W[sbase] = (uint32_t)r | (nops << 8) | (nwords << 16);
+      ++nstages;
+      pool = rest;
+    }
+    W[base + PW_NSTAGES] = nstages;
+  }
+  W[PH_TOTAL] = (uint32_t)W.size();
+  plan.n = n; plan.k = k; plan.r = r; plan.n_passes = np; plan.n_fused = (int)fused.size();
+  plan.n_params = spec.n_params; plan.threads = threads; plan.n_gates = spec.n_gates;
+  return true;
+}
+}  // namespace
+
+}  // namespace bornvi

@@ -1,0 +1,98 @@
+// Circuit execution planner (host side).
+//
+// Turns an ansatz (gate order of quantum_born_machine.py:57-128) into a small program
+// for the LDS-tiled statevector kernel:
+//
+//   gates --fuse--> ops (U1 = fused one-qubit unitary, CX, CZ)
+//         --passes--> each pass makes `k` of the n wires tile-local (a 2^k-amplitude
+//                     tile lives in one workgroup's LDS); ops whose non-diagonal target is
+//                     local run in that pass; the tile is re-laid-out on the way back to
+//                     HBM so that the next pass finds ITS wires local and its lowest
+//                     physical bits contiguous (coalesced 1 KiB runs);
+//         --stages--> inside a pass every thread keeps 2^r amplitudes in registers
+//                     (r register wires); one LDS round trip per stage.
+//
+// The serialised plan is a flat uint32 array read by the kernels with wave-uniform
+// (scalar) loads.  Layout constants below are shared with kernels_circuit.hip and with the
+// Python plan emulator in tests/.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace bornvi {
+
+enum GateKind : int { G_H = 0, G_RX = 1, G_RY = 2, G_RZ = 3, G_CNOT = 4, G_CZ = 5 };
+
+struct Gate {
+  int kind;
+  int w0;     // wire (1q) or control / first wire
+  int w1;     // target / second wire, -1 for 1q gates
+  int param;  // parameter index or -1
+};
+
+int num_params(int ansatz, int n, int layers);
+// false if ansatz is unknown
+bool build_gate_list(int ansatz, int n, int layers, std::vector<Gate>& out);
+
+// ---- serialised plan layout (uint32 words) --------------------------------------------------
+constexpr uint32_t PLAN_MAGIC = 0x424e5649u;  // "BNVI"
+enum PlanHeader : int {
+  PH_MAGIC = 0, PH_N, PH_K, PH_NPASSES, PH_NFUSED, PH_NPARAMS, PH_OFF_FUSED, PH_OFF_PASSTAB,
+  PH_TOTAL, PH_THREADS, PH_R, PH_NGATES, PH_SIZE = 16
+};
+// fused one-qubit gate: FUSED_WORDS words each
+//   [0] wire  [1] n_elem  [2+2e] kind_e  [3+2e] param_e   (e < FUSED_MAX_ELEMS), applied e = 0 first
+constexpr int FUSED_MAX_ELEMS = 4;
+constexpr int FUSED_WORDS = 2 + 2 * FUSED_MAX_ELEMS;
+// pass descriptor
+enum PassWords : int {
+  PW_FLAGS = 0, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS, PW_RESERVED,
+  PW_IN_PHYS = 8,       // [32] phys-in bit position of LDS bit j
+  PW_IN_GPHYS = 40,     // [32] phys-in bit position of workgroup-index bit m
+  PW_OUT_LDS = 72,      // [32] LDS bit position of out-enumeration bit j
+  PW_OUT_PHYS = 104,    // [32] phys-out bit position of out-enumeration bit j
+  PW_OUT_GPHYS = 136,   // [32] phys-out bit position of workgroup-index bit m
+  PW_WIRE_OF_LDS = 168, // [32] wire held by LDS bit j        (informational / emulator)
+  PW_WIRE_OF_G = 200,   // [32] wire held by workgroup bit m  (informational / emulator)
+  PW_STAGES = 232
+};
+constexpr uint32_t PASS_INIT = 1u;   // tile starts as |0...0> (no HBM read)
+constexpr uint32_t PASS_FINAL = 2u;  // epilogue writes |psi|^2 in canonical order
+constexpr uint32_t PASS_FINAL_STATE = 4u;  // epilogue writes the state itself in canonical order
+// stage: [0] r | nops << 8 | nwords << 16   [1] rho (4 bytes: LDS bit of register bit i)
+//        [2..5] tpos (16 bytes: LDS bit receiving thread bit j)   [6..] ops
+constexpr int STAGE_HDR_WORDS = 6;
+// op word: kind (bits 0-3) | a (bits 4-9) | b (bits 10-15) | idx (bits 16-31)
+enum OpKind : uint32_t {
+  OP_U1 = 1,     // a = register bit, idx = fused gate index
+  OP_CX_RR = 2,  // a = control register bit, b = target register bit
+  OP_CX_AR = 3,  // a = control position in the extended index, b = target register bit
+  OP_SIGNQ = 4   // followed by SIGNQ_WORDS words
+};
+// SIGNQ payload: [0..31] U rows (upper-triangular adjacency over extended index bits),
+//                [32..47] m_j (bilinear masks of the 16 register offsets), [48] q bits of the offsets
+constexpr int SIGNQ_WORDS = 49;
+
+struct PlanOptions {
+  int kmax = 13;     // tile bits (2^13 complex128 = 128 KiB of LDS)
+  int r = 4;         // register wires per stage (2^4 amplitudes per thread)
+  int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
+  int max_threads = 512;
+};
+
+struct Plan {
+  int n = 0, k = 0, r = 0, n_passes = 0, n_fused = 0, n_params = 0, threads = 0, n_gates = 0;
+  std::vector<uint32_t> words;
+  std::vector<uint32_t> pass_off;  // word offset of each pass descriptor
+  size_t lds_bytes() const { return (size_t(1) << k) * 16; }
+};
+
+// Returns false (with msg) on unsupported sizes.
+bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& out, std::string& msg);
+// Program applying one shared 2x2 matrix to every bit of a canonical-order vector (state in,
+// state out); used by the matrix-free Stein mat-vec (K_base = M^{(x) n}).
+bool make_kron_plan(int n, const PlanOptions& opt, Plan& out, std::string& msg);
+
+}  // namespace bornvi

@@ -1,0 +1,44 @@
+"""Sharding of the 2P parameter-shift circuit evaluations across the GPUs of one node.
+
+The shifted circuits of a training step are independent given theta and dL/dq, so rank r of W
+evaluates the parameters [r*ceil(P/W), ...) and the per-parameter gradient scalars (8 bytes
+each) are exchanged with ONE all-gather per step (RCCL over xGMI when the process group uses the
+'nccl' backend; 'gloo' in the CPU tests).  theta, optimiser state, S and K_p are replicated, and
+every rank applies the identical update, so no broadcast is needed.
+
+The reference has no distributed code; this is a new design.  Note that
+what is gathered are GRADIENT scalars 1/2 dLdq.(q+ - q-), not shifted KSD values: the KSD is
+quadratic in q, so the two-term shift rule does not apply to it directly.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world(group=None):
+    """(rank, world_size) of `group`, or (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(num_params, rank, world_size):
+    """Contiguous slice of parameters owned by `rank`; equal-sized chunks of ceil(P/W) (the last
+    ranks may own fewer, or none)."""
+    chunk = -(-num_params // world_size)
+    lo = min(num_params, rank * chunk)
+    hi = min(num_params, lo + chunk)
+    return lo, hi
+
+
+def all_gather_grad(local_grad, num_params, group=None):
+    """local_grad: this rank's slice (float64, any device the backend supports) -> full [P] vector,
+    identical on every rank."""
+    rank, ws = world(group)
+    if ws == 1:
+        return local_grad
+    chunk = -(-num_params // ws)
+    padded = torch.zeros(chunk, dtype=local_grad.dtype, device=local_grad.device)
+    padded[: local_grad.numel()] = local_grad
+    full = torch.empty(chunk * ws, dtype=local_grad.dtype, device=local_grad.device)
+    dist.all_gather_into_tensor(full, padded, group=group)
+    return full[:num_params]

@@ -1,0 +1,169 @@
+"""NumPy emulator of the circuit execution plan (test infrastructure only).
+
+Interprets the uint32 plan produced by the C++ planner (bornvi_plan_describe) exactly as
+circuit_pass_kernel does -- same tile/bit-permutation arithmetic, same stage/thread/register
+decomposition, same micro-ops -- but on NumPy arrays, so that the planner can be validated
+against the oracle without a GPU.  (The LDS swizzle is an address-only detail and is skipped.)
+"""
+import numpy as np
+
+from oracle import circuit as oc
+
+PH_N, PH_K, PH_NPASSES, PH_NFUSED, PH_NPARAMS, PH_OFF_FUSED, PH_OFF_PASSTAB, PH_TOTAL, PH_THREADS, PH_R, PH_NGATES = range(1, 12)
+FUSED_WORDS = 10
+PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
+PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_LDS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_STAGES = 8, 40, 72, 104, 136, 168, 200, 232
+PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
+STAGE_HDR_WORDS = 6
+OP_U1, OP_CX_RR, OP_CX_AR, OP_SIGNQ = 1, 2, 3, 4
+SIGNQ_WORDS = 49
+KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
+
+
+def fused_matrices(W, theta):
+    nf = int(W[PH_NFUSED]); off = int(W[PH_OFF_FUSED])
+    mats = []
+    for f in range(nf):
+        fw = W[off + f * FUSED_WORDS: off + (f + 1) * FUSED_WORDS]
+        U = np.eye(2, dtype=np.complex128)
+        for e in range(int(fw[1])):
+            kind, par = int(fw[2 + 2 * e]), int(fw[3 + 2 * e])
+            t = None if par == 0xFFFFFFFF else theta[par]
+            U = oc.matrix_1q(KIND_NAMES[kind], t) @ U
+        mats.append(U)
+    return mats
+
+
+def popc(x):
+    x = np.asarray(x, dtype=np.uint64)
+    c = np.zeros(x.shape, dtype=np.uint64)
+    for s in range(32):
+        c += (x >> np.uint64(s)) & np.uint64(1)
+    return c
+
+
+def run_plan(W, mats, state_in=None):
+    """Returns probabilities (PASS_FINAL) or the final state (PASS_FINAL_STATE), canonical order."""
+    W = np.asarray(W, dtype=np.uint32)
+    n, k, np_ = int(W[PH_N]), int(W[PH_K]), int(W[PH_NPASSES])
+    N = 1 << n
+    buf = None if state_in is None else np.asarray(state_in, dtype=np.complex128).copy()
+    result = None
+    for pi in range(np_):
+        P = W[int(W[int(W[PH_OFF_PASSTAB]) + pi]):]
+        flags = int(P[PW_FLAGS]); T = int(P[PW_THREADS]); nst = int(P[PW_NSTAGES])
+        lo_in, lo_out = int(P[PW_LO_IN]), int(P[PW_LO_OUT])
+        assert int(P[PW_K]) == k and int(P[PW_N]) == n
+        ksize = 1 << k
+        out = np.zeros(N, dtype=np.complex128)
+        probs = np.zeros(N)
+        # structural checks the kernel relies on
+        for j in range(lo_in):
+            assert (flags & PASS_INIT) or int(P[PW_IN_PHYS + j]) == j
+        for j in range(lo_out):
+            assert int(P[PW_OUT_PHYS + j]) == j
+        for g in range(1 << (n - k)):
+            u = np.arange(ksize, dtype=np.int64)
+            if flags & PASS_INIT:
+                tile = np.zeros(ksize, dtype=np.complex128)
+                if g == 0:
+                    tile[0] = 1.0
+            else:
+                phys = np.zeros(ksize, dtype=np.int64)
+                for j in range(k):
+                    phys |= ((u >> j) & 1) << int(P[PW_IN_PHYS + j])
+                for m in range(n - k):
+                    phys |= ((g >> m) & 1) << int(P[PW_IN_GPHYS + m])
+                tile = buf[phys]
+            S = P[PW_STAGES:]
+            for _ in range(nst):
+                hdr = int(S[0]); r = hdr & 0xFF; nops = (hdr >> 8) & 0xFF; nwords = hdr >> 16
+                rho = int(S[1])
+                nthr = 1 << (k - r)
+                assert nthr <= T
+                t = np.arange(nthr, dtype=np.int64)
+                base = np.zeros(nthr, dtype=np.int64)
+                for j in range(k - r):
+                    pos = (int(S[2 + (j >> 2)]) >> (8 * (j & 3))) & 0xFF
+                    base |= ((t >> j) & 1) << pos
+                rpos = [(rho >> (8 * i)) & 0xFF for i in range(r)]
+                nreg = 1 << r
+                offs = [sum(((j >> i) & 1) << rpos[i] for i in range(r)) for j in range(nreg)]
+                # every LDS element is owned by exactly one (thread, register) pair
+                own = np.concatenate([base ^ o for o in offs])
+                assert np.array_equal(np.sort(own), np.arange(ksize))
+                amp = [tile[base ^ o].copy() for o in offs] + [np.zeros(nthr, np.complex128)] * (16 - nreg)
+                e = base | (g << k)
+                op = STAGE_HDR_WORDS
+                for _o in range(nops):
+                    w = int(S[op]); op += 1
+                    kind, a, b, idx = w & 15, (w >> 4) & 63, (w >> 10) & 63, w >> 16
+                    if kind == OP_U1:
+                        U = mats[idx]
+                        assert a < r
+                        for j in range(nreg):
+                            if j & (1 << a):
+                                continue
+                            j1 = j | (1 << a)
+                            x0, x1 = amp[j], amp[j1]
+                            amp[j], amp[j1] = U[0, 0] * x0 + U[0, 1] * x1, U[1, 0] * x0 + U[1, 1] * x1
+                    elif kind == OP_CX_RR:
+                        assert a < r and b < r and a != b
+                        for j in range(nreg):
+                            if (j & (1 << a)) and not (j & (1 << b)):
+                                j1 = j | (1 << b)
+                                amp[j], amp[j1] = amp[j1], amp[j]
+                    elif kind == OP_CX_AR:
+                        assert b < r and a < n and a not in rpos
+                        c = ((e >> a) & 1).astype(bool)
+                        for j in range(nreg):
+                            if not (j & (1 << b)):
+                                j1 = j | (1 << b)
+                                a0, a1 = amp[j], amp[j1]
+                                amp[j], amp[j1] = np.where(c, a1, a0), np.where(c, a0, a1)
+                    elif kind == OP_SIGNQ:
+                        Q = S[op: op + SIGNQ_WORDS]
+                        acc = np.zeros(nthr, dtype=np.uint64)
+                        for q in range(n):
+                            row = int(Q[q])
+                            acc ^= ((e >> q) & 1).astype(np.uint64) & popc(e & row)
+                        qbits = int(Q[48])
+                        for j in range(nreg):
+                            sgn = (((qbits >> j) & 1) ^ (acc & np.uint64(1)) ^ (popc(e & int(Q[32 + j])) & np.uint64(1))).astype(bool)
+                            amp[j] = np.where(sgn, -amp[j], amp[j])
+                        op += SIGNQ_WORDS
+                    else:
+                        raise AssertionError(f"bad op kind {kind}")
+                assert op == nwords, (op, nwords)
+                for j in range(nreg):
+                    tile[base ^ offs[j]] = amp[j]
+                S = S[nwords:]
+            # store
+            v = np.arange(ksize, dtype=np.int64)
+            lds = np.zeros(ksize, dtype=np.int64)
+            phys = np.zeros(ksize, dtype=np.int64)
+            for j in range(k):
+                lds |= ((v >> j) & 1) << int(P[PW_OUT_LDS + j])
+                phys |= ((v >> j) & 1) << int(P[PW_OUT_PHYS + j])
+            for m in range(n - k):
+                phys |= ((g >> m) & 1) << int(P[PW_OUT_GPHYS + m])
+            assert np.array_equal(np.sort(lds), np.arange(ksize))
+            if flags & PASS_FINAL:
+                probs[phys] = np.abs(tile[lds]) ** 2
+            else:
+                out[phys] = tile[lds]
+        buf = out
+        if flags & PASS_FINAL:
+            result = probs
+        elif flags & PASS_FINAL_STATE:
+            result = out
+    return result
+
+
+def plan_stats(W):
+    n, k, np_ = int(W[PH_N]), int(W[PH_K]), int(W[PH_NPASSES])
+    stages = []
+    for pi in range(np_):
+        P = W[int(W[int(W[PH_OFF_PASSTAB]) + pi]):]
+        stages.append(int(P[PW_NSTAGES]))
+    return {"n": n, "k": k, "passes": np_, "stages": stages, "fused": int(W[PH_NFUSED]), "gates": int(W[PH_NGATES])}

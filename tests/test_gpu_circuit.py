@@ -1,0 +1,180 @@
+"""GPU parity of the circuit engine (through the C ABI) against the CPU oracle.
+
+Tolerance: q_theta within 1e-10 relative / 1e-14 absolute of the oracle (north_star asks 1e-6
+relative, fp64); fp64 throughout."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import circuit as oc
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-10, 1e-14
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture()
+def be(dev):
+    from tensornetworks_amd import backend
+    yield backend
+    backend.set_option(dev, "tile_bits", 13)
+
+
+def gpu_probs(be, dev, ansatz, n, L, thetas):
+    t = torch.as_tensor(np.atleast_2d(thetas), dtype=torch.float64, device=dev).contiguous()
+    return be.circuit_probs(ansatz, n, L, t).cpu().numpy()
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L", [(1, 1), (2, 2), (3, 4), (4, 1), (5, 3), (8, 4), (10, 2), (12, 4), (13, 2)])
+def test_probs_match_oracle_single_pass(be, dev, ansatz, n, L):
+    rng = np.random.default_rng(100 * n + L)
+    th = rng.uniform(-np.pi, np.pi, (3, oc.num_params(ansatz, n, L)))
+    q = gpu_probs(be, dev, ansatz, n, L, th)
+    for b in range(3):
+        np.testing.assert_allclose(q[b], oc.probs(ansatz, n, L, th[b]), rtol=RTOL, atol=ATOL)
+        assert abs(q[b].sum() - 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb", [(6, 3, 4), (9, 3, 6), (10, 2, 7), (12, 2, 9), (14, 3, 13), (15, 2, 12), (16, 2, 13)])
+def test_probs_match_oracle_multi_pass(be, dev, ansatz, n, L, kb):
+    """Tiles smaller than the state: several passes with HBM re-layout in between."""
+    be.set_option(dev, "tile_bits", kb)
+    rng = np.random.default_rng(7 * n + L + kb)
+    th = rng.uniform(-np.pi, np.pi, (2, oc.num_params(ansatz, n, L)))
+    q = gpu_probs(be, dev, ansatz, n, L, th)
+    for b in range(2):
+        np.testing.assert_allclose(q[b], oc.probs(ansatz, n, L, th[b]), rtol=RTOL, atol=ATOL)
+
+
+def test_known_answers(be, dev):
+    # theta = 0 -> uniform (hardware_efficient / all_to_all), delta (basic)
+    for ansatz in ("hardware_efficient", "all_to_all"):
+        q = gpu_probs(be, dev, ansatz, 6, 3, np.zeros(oc.num_params(ansatz, 6, 3)))[0]
+        np.testing.assert_allclose(q, np.full(64, 1 / 64), atol=1e-15)
+    q = gpu_probs(be, dev, "basic", 5, 2, np.zeros(oc.num_params("basic", 5, 2)))[0]
+    e = np.zeros(32); e[0] = 1
+    np.testing.assert_allclose(q, e, atol=1e-15)
+    # n = 1 closed form, independent of the RX / RZ angles
+    q = gpu_probs(be, dev, "hardware_efficient", 1, 1, [0.3, 0.9, -1.1])[0]
+    np.testing.assert_allclose(q, [(1 - math.sin(0.9)) / 2, (1 + math.sin(0.9)) / 2], atol=1e-15)
+    # n = 2 basic: pins CNOT direction and MSB ordering
+    t = [0.4, 0.2, 1.3, 0.5]
+    q = gpu_probs(be, dev, "basic", 2, 1, t)[0]
+    c0, s0 = math.cos(t[0] / 2) ** 2, math.sin(t[0] / 2) ** 2
+    c1, s1 = math.cos(t[2] / 2) ** 2, math.sin(t[2] / 2) ** 2
+    np.testing.assert_allclose(q, [c0 * c1, c0 * s1, s0 * s1, s0 * c1], atol=1e-15)
+
+
+def test_zero_layers_and_large_batch(be, dev):
+    q = gpu_probs(be, dev, "hardware_efficient", 4, 0, np.zeros((2, 0)))
+    np.testing.assert_allclose(q, np.full((2, 16), 1 / 16), atol=1e-15)      # only the Hadamards
+    rng = np.random.default_rng(1)
+    th = rng.uniform(-1, 1, (300, oc.num_params("basic", 7, 2)))
+    q = gpu_probs(be, dev, "basic", 7, 2, th)
+    np.testing.assert_allclose(q, oc.probs_batched("basic", 7, 2, th), rtol=RTOL, atol=ATOL)
+
+
+def test_workspace_chunking(be, dev, monkeypatch):
+    """A workspace that holds fewer circuits than the batch makes the library loop over chunks."""
+    n, L = 14, 1
+    be.set_option(dev, "tile_bits", 12)            # multi-pass => states live in the workspace
+    rng = np.random.default_rng(3)
+    th = rng.uniform(-1, 1, (5, oc.num_params("hardware_efficient", n, L)))
+    full = gpu_probs(be, dev, "hardware_efficient", n, L, th)
+    monkeypatch.setattr(be, "WORKSPACE_CAP", 2 * (2 * 16 * (1 << n)) + 40000)   # room for ~2 circuits
+    be.release_workspaces()
+    chunked = gpu_probs(be, dev, "hardware_efficient", n, L, th)
+    np.testing.assert_array_equal(full, chunked)
+    be.release_workspaces()
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L", [(3, 2), (5, 2), (8, 1)])
+def test_paramshift_grad_matches_oracle(be, dev, ansatz, n, L):
+    rng = np.random.default_rng(n + L)
+    P = oc.num_params(ansatz, n, L)
+    th = rng.uniform(-1, 1, P)
+    w = rng.normal(size=2 ** n)
+    g_o = oc.paramshift_vjp(ansatz, n, L, th, w)
+    tht = torch.as_tensor(th, device=dev)
+    wt = torch.as_tensor(w, device=dev)
+    g = be.paramshift_grad(ansatz, n, L, tht, wt, 0, P).cpu().numpy()
+    np.testing.assert_allclose(g, g_o, rtol=1e-9, atol=1e-12 * np.abs(g_o).max())
+    # a slice of the parameters (what one rank of a sharded step computes)
+    lo, hi = P // 3, 2 * P // 3
+    gs = be.paramshift_grad(ansatz, n, L, tht, wt, lo, hi).cpu().numpy()
+    np.testing.assert_array_equal(gs, g[lo:hi])
+    # shifted probabilities layout: base, then (+p, -p)
+    pr = be.paramshift_probs(ansatz, n, L, tht, 1, 3, include_base=True).cpu().numpy()
+    np.testing.assert_allclose(pr[0], oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)
+    tp = th.copy(); tp[2] += np.pi / 2
+    tm = th.copy(); tm[2] -= np.pi / 2
+    np.testing.assert_allclose(pr[3], oc.probs(ansatz, n, L, tp), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(pr[4], oc.probs(ansatz, n, L, tm), rtol=RTOL, atol=ATOL)
+
+
+def test_unfused_gate_kernels(be, dev):
+    n, B = 9, 5
+    rng = np.random.default_rng(0)
+    psi = rng.normal(size=(B, 2 ** n)) + 1j * rng.normal(size=(B, 2 ** n))
+    psi /= np.linalg.norm(psi, axis=1, keepdims=True)
+    for wire in (0, 4, 8):
+        U = oc.matrix_1q("RY", 0.3) @ oc.matrix_1q("RZ", -0.7) @ oc.matrix_1q("RX", 1.1)
+        st = torch.as_tensor(psi, device=dev).contiguous()
+        be.gate1q_apply(st, n, wire, U)
+        ref = np.stack([oc.apply_1q(p.reshape((2,) * n), U, wire).reshape(-1) for p in psi])
+        np.testing.assert_allclose(st.cpu().numpy(), ref, rtol=0, atol=1e-15)
+    for c, t in ((0, 8), (8, 0), (3, 4)):
+        st = torch.as_tensor(psi, device=dev).contiguous()
+        be.cnot_apply(st, n, c, t)
+        ref = np.stack([oc.apply_cnot(p.reshape((2,) * n), c, t).reshape(-1) for p in psi])
+        np.testing.assert_array_equal(st.cpu().numpy(), ref)
+    st = torch.as_tensor(psi, device=dev).contiguous()
+    np.testing.assert_allclose(be.born_probs(st, n).cpu().numpy(), np.abs(psi) ** 2, rtol=1e-15)
+
+
+def test_full_size_properties(be, dev):
+    """BASELINE config 3 size (n = 16, L = 6): normalisation, agreement of the fused engine with a
+    gate-by-gate run of the un-fused kernels, and parameter-shift == finite difference."""
+    n, L, ansatz = 16, 6, "hardware_efficient"
+    P = oc.num_params(ansatz, n, L)
+    g = torch.Generator().manual_seed(0)
+    th = (0.1 * torch.randn(P, generator=g, dtype=torch.float32)).double()
+    tht = th.to(dev)
+    q = be.circuit_probs(ansatz, n, L, tht.view(1, -1))[0]
+    assert abs(q.sum().item() - 1.0) < 1e-12
+    # gate-by-gate on the device with the un-fused kernels (independent code path)
+    st = torch.zeros((1, 2 ** n), dtype=torch.complex128, device=dev)
+    st[0, 0] = 1.0
+    thn = th.numpy()
+    for kind, wires, p in oc.gate_list(ansatz, n, L):
+        if kind == "CNOT":
+            be.cnot_apply(st, n, wires[0], wires[1])
+        elif kind == "CZ":                                       # CZ = H_t CNOT H_t
+            be.gate1q_apply(st, n, wires[1], oc.matrix_1q("H"))
+            be.cnot_apply(st, n, wires[0], wires[1])
+            be.gate1q_apply(st, n, wires[1], oc.matrix_1q("H"))
+        else:
+            be.gate1q_apply(st, n, wires[0], oc.matrix_1q(kind, None if p is None else thn[p]))
+    np.testing.assert_allclose(q.cpu().numpy(), be.born_probs(st, n)[0].cpu().numpy(), rtol=1e-9, atol=1e-16)
+    np.testing.assert_allclose(q.cpu().numpy(), oc.probs(ansatz, n, L, thn), rtol=1e-9, atol=1e-16)
+    # parameter-shift gradient of a linear functional == central finite difference (3 parameters)
+    w = torch.randn(2 ** n, generator=g, dtype=torch.float64).to(dev)
+    for p in (0, P // 2, P - 1):
+        gp = be.paramshift_grad(ansatz, n, L, tht, w, p, p + 1).item()
+        h = 1e-5
+        tp = tht.clone(); tp[p] += h
+        tm = tht.clone(); tm[p] -= h
+        qq = be.circuit_probs(ansatz, n, L, torch.stack([tp, tm]))
+        fd = ((qq[0] - qq[1]) @ w).item() / (2 * h)
+        assert abs(gp - fd) < 1e-7 * max(1.0, abs(fd))

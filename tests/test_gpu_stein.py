@@ -1,0 +1,179 @@
+"""GPU parity of the Stein side (score, Gram, quadratic form, matrix-free mat-vec, per-element API)
+against the golden vectors captured from the reference and against the CPU oracle."""
+import math
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stein as os_, ksd as ok
+from tensornetworks_amd.bayesian_network import (BayesianNetwork, get_sprinkler_network, pack_network,
+                                                  synthetic_network)
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def be():
+    from tensornetworks_amd import backend
+    return backend
+
+
+def two_node():
+    bn = BayesianNetwork()
+    bn.add_node('A', cpt={(): {0: 0.8, 1: 0.2}})
+    bn.add_node('B', cpt={(0,): {0: 0.7, 1: 0.3}, (1,): {0: 0.4, 1: 0.6}}, parent_names=['A'])
+    return bn
+
+
+@pytest.mark.parametrize("name", ["sprinkler_w1", "sprinkler_w0", "sprinkler_rand0", "sprinkler_rand1",
+                                  "sprinkler_rand2", "synthetic_n4_s0", "synthetic_n5_s0", "synthetic_n5_s1",
+                                  "synthetic_n6_s0", "synthetic_n8_s0", "two_node"])
+def test_score_and_gram_golden(be, dev, name):
+    """S bit-exact (same fp64 operation order as the reference); K_p within 3e-15 of max|K|."""
+    g = golden(name + ".npz")
+    n = g["S"].shape[1]
+    if name == "two_node":
+        packed = pack_network(two_node(), ['A'], {'B': 1})
+    else:
+        packed = {k[5:]: g[k] for k in g.files if k.startswith("pack_")}
+    S, pxz = be.score_from_packed(packed, n, dev)
+    np.testing.assert_array_equal(S.cpu().numpy(), g["S"])
+    np.testing.assert_array_equal(pxz.cpu().numpy(), g["pxz"])
+    K = be.stein_gram(S, n, 1.0).cpu().numpy()
+    rows = g["rows"] if "rows" in g.files else np.arange(2 ** n)
+    np.testing.assert_allclose(K[rows], g["K"], rtol=0, atol=3e-15 * np.abs(g["K"]).max())
+    assert np.array_equal(K, K.T)                       # evaluated symmetrically: bitwise symmetric
+
+
+def test_hidden_nodes_are_marginalised(be, dev):
+    """Latents (C, R), observed W, Sprinkler node S summed out (stein_utils.py:95-111)."""
+    bn = get_sprinkler_network(False)
+    lat, x = ['C', 'R'], {'W': 1}
+    S, pxz = be.score_from_packed(pack_network(bn, lat, x), 2, dev)
+    np.testing.assert_array_equal(S.cpu().numpy(), os_.score_matrix(bn, x, lat))
+    np.testing.assert_array_equal(pxz.cpu().numpy(), os_.joint_vector(bn, x, lat))
+
+
+def test_degenerate_score_is_zero(be, dev):
+    """|p(x,z)| < 1e-12 -> zero score vector (stein_utils.py:126-128)."""
+    bn = BayesianNetwork()
+    bn.add_node('A', cpt={(): {0: 1.0, 1: 0.0}})
+    bn.add_node('B', cpt={(0,): {0: 0.5, 1: 0.5}, (1,): {0: 0.5, 1: 0.5}}, parent_names=['A'])
+    S, pxz = be.score_from_packed(pack_network(bn, ['A'], {'B': 1}), 1, dev)
+    So = os_.score_matrix(bn, {'B': 1}, ['A'])
+    np.testing.assert_array_equal(S.cpu().numpy(), So)
+    assert S[1, 0].item() == 0.0
+
+
+@pytest.mark.parametrize("n,seed", [(3, 0), (6, 0), (9, 1), (11, 2)])
+def test_quadform_and_kron_match_oracle(be, dev, n, seed):
+    bn, lat, obs, x = synthetic_network(n, seed)
+    S, pxz = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    So = S.cpu().numpy()
+    Ko = os_.gram_closed_form(So, n) if n <= 9 else None
+    K = be.stein_gram(S, n, 1.0)
+    if Ko is not None:
+        np.testing.assert_allclose(K.cpu().numpy(), Ko, rtol=0, atol=3e-15 * np.abs(Ko).max())
+    Kn = K.cpu().numpy()
+    rng = np.random.default_rng(seed)
+    Q = rng.random((3, 2 ** n)); Q /= Q.sum(1, keepdims=True)
+    Qt = torch.as_tensor(Q, device=dev)
+    ksd2, Y = be.stein_quadform(K, Qt, n)
+    scale = np.abs(Kn).max()
+    np.testing.assert_allclose(Y.cpu().numpy(), Q @ Kn.T, rtol=0, atol=1e-13 * scale)
+    for b in range(3):
+        ref = Q[b] @ Kn @ Q[b]
+        tol = 1e-13 * float(np.abs(Q[b][:, None] * Q[b][None, :] * Kn).sum())
+        assert abs(ksd2[b].item() - ref) < tol
+        k2, y = be.stein_matvec_kron(S, Qt[b].contiguous(), n, 1.0)
+        np.testing.assert_allclose(y.cpu().numpy(), Kn @ Q[b], rtol=0, atol=1e-12 * scale)
+        assert abs(k2.item() - ref) < 10 * tol
+    # only ksd2 requested
+    k_only, none = be.stein_quadform(K, Qt, n, want_y=False)
+    assert none is None
+    np.testing.assert_array_equal(k_only.cpu().numpy(), ksd2.cpu().numpy())
+
+
+def test_length_scale(be, dev):
+    g = golden("synthetic_n5_s0.npz")
+    S = torch.as_tensor(g["S"], device=dev)
+    for ls in (0.5, 2.0):
+        K = be.stein_gram(S, 5, ls).cpu().numpy()
+        np.testing.assert_allclose(K, os_.gram_closed_form(g["S"], 5, ls), rtol=0, atol=3e-15 * np.abs(K).max())
+        np.testing.assert_allclose(K, os_.gram_loop(g["S"], 5, ls), rtol=0, atol=1e-12 * np.abs(K).max())
+    from tensornetworks_amd._ext import BornviError
+    with pytest.raises(BornviError):
+        be.stein_gram(S, 5, 0.0)
+
+
+def test_reference_known_answers_through_dropin_api(dev):
+    """The seven assertions of stein_utils.py:205-251 against the drop-in functions."""
+    from tensornetworks_amd import stein_utils as su
+    t64 = torch.float64
+    assert su.flip_bit((0, 0, 0), 0) == (1, 0, 0)
+    z1 = torch.tensor([0, 0, 1, 1], dtype=t64); z2 = torch.tensor([1, 0, 0, 1], dtype=t64)
+    assert su.hamming_distance_torch(z1, z2).item() == 2.0
+    assert torch.isclose(su.base_hamming_kernel_torch(z1, z2, 4, length_scale=1.0), torch.tensor(np.exp(-0.5), dtype=t64))
+    bn = two_node()
+    lat, obs, x = ['A'], ['B'], {'B': 1}
+    assert np.isclose(su.compute_prob_joint_xz(bn, x, (1,), lat, obs), 0.12)
+    s1 = su.get_score_function_sp_for_z(bn, x, (1,), lat, obs, device='cpu')
+    s0 = su.get_score_function_sp_for_z(bn, x, (0,), lat, obs, device='cpu')
+    assert s1.dtype == t64 and torch.isclose(s1[0], torch.tensor(-1.0, dtype=t64))
+    assert torch.isclose(s0[0], torch.tensor(0.5, dtype=t64))
+    kf = partial(su.base_hamming_kernel_torch, num_vars=1, length_scale=1.0)
+    kp01 = su.get_stein_kernel_kp_value((0,), (1,), x, bn, lat, obs, kf, s0, s1, device='cpu')
+    kp00 = su.get_stein_kernel_kp_value((0,), (0,), x, bn, lat, obs, kf, s0, s0, device='cpu')
+    assert torch.isclose(kp01, torch.tensor(2 * np.exp(-1.0) - 2.5, dtype=t64))
+    assert torch.isclose(kp00, torch.tensor(1.25 - np.exp(-1.0), dtype=t64))
+    with pytest.raises(TypeError):
+        su.get_stein_kernel_kp_value((0,), (1,), x, bn, lat, obs, lambda a, b: 1.0, s0, s1)
+    # special cases of the base kernel (:36-40, :52-54)
+    assert su.base_hamming_kernel_torch(torch.zeros(0), torch.zeros(0), 0).item() == 1.0
+    assert su.base_hamming_kernel_torch(z1, z1, 4, length_scale=0.0).item() == 1.0
+    assert su.base_hamming_kernel_torch(z1, z2, 4, length_scale=0.0).item() == 0.0
+
+
+def test_kp_pairs_match_gram(be, dev):
+    g = golden("synthetic_n6_s0.npz")
+    S = torch.as_tensor(g["S"], device=dev)
+    rng = np.random.default_rng(0)
+    zi = torch.as_tensor(rng.integers(0, 64, 200), device=dev)
+    zj = torch.as_tensor(rng.integers(0, 64, 200), device=dev)
+    out = be.stein_kp_pairs(6, 1.0, zi, zj, S[zi].contiguous(), S[zj].contiguous()).cpu().numpy()
+    np.testing.assert_allclose(out, g["K"][zi.cpu().numpy(), zj.cpu().numpy()], rtol=0, atol=3e-15 * np.abs(g["K"]).max())
+
+
+def test_full_size_gram_properties(be, dev):
+    """n = 16 (BASELINE config 3): the 32 GiB dense Gram against size-independent properties:
+    K p(z|x) ~ 0, q^T K q from the dense GEMV == the matrix-free Kronecker mat-vec, sampled
+    entries == the per-pair kernel, sampled rows symmetric."""
+    n = 16
+    bn, lat, obs, x = synthetic_network(n, 0)
+    S, pxz = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    K = be.stein_gram(S, n, 1.0)
+    kmax = K[:64].abs().max().item()
+    post = (pxz / pxz.sum()).contiguous()
+    k2p, yp = be.stein_quadform(K, post, n)
+    assert yp.abs().max().item() < 1e-9 * max(kmax, 1.0)
+    g = torch.Generator().manual_seed(5)
+    q = torch.rand(2 ** n, generator=g, dtype=torch.float64).to(dev)
+    q /= q.sum()
+    k2d, yd = be.stein_quadform(K, q, n)
+    k2k, yk = be.stein_matvec_kron(S, q, n, 1.0)
+    assert abs(k2d.item() - k2k.item()) <= 1e-9 * abs(k2d.item())
+    assert (yd[0] - yk).abs().max().item() <= 1e-10 * yd.abs().max().item()
+    idx = torch.randint(0, 2 ** n, (4096,), generator=g).to(dev)
+    jdx = torch.randint(0, 2 ** n, (4096,), generator=g).to(dev)
+    pairs = be.stein_kp_pairs(n, 1.0, idx, jdx, S[idx].contiguous(), S[jdx].contiguous())
+    assert (pairs - K[idx, jdx]).abs().max().item() <= 1e-13 * max(pairs.abs().max().item(), 1.0)
+    assert torch.equal(K[idx, jdx], K[jdx, idx])

@@ -1,0 +1,149 @@
+"""GPU parity of the drop-in classes (QuantumBornMachine, KSDVariationalInference) against the oracle's
+restatement of the reference epoch (ksd_vi_quantum.py:110-161)."""
+import io
+import contextlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import circuit as oc, stein as os_, ksd as ok
+from tensornetworks_amd.bayesian_network import get_sprinkler_network, synthetic_network
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def make_vi(bn, lat, obs, n, L, ansatz, device, seed=0, **kw):
+    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+    torch.manual_seed(seed)
+    return KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=L,
+                                   qbm_ansatz_type=ansatz, pytorch_device=device, **kw)
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda:0"])
+@pytest.mark.parametrize("optimizer_type", ["adam", "sgd"])
+def test_five_epoch_trace_sprinkler(dev, device, optimizer_type):
+    """Run script defaults (run_sprinkler_quantum_ksd.py:35-43): n=3, L=4, hardware_efficient, lr 0.005,
+    clip 10, cosine schedule.  theta lives on `device`; the circuits always run on the GPU."""
+    bn = get_sprinkler_network(False)
+    lat, obs, x = ['C', 'S', 'R'], ['W'], {'W': 1}
+    vi = make_vi(bn, lat, obs, 3, 4, "hardware_efficient", device, seed=11)
+    theta0 = vi.born_machine.theta.detach().cpu().numpy().copy()
+    assert vi.born_machine.theta.dtype == torch.float32 and theta0.shape == (36,)
+    post, _ = bn.get_true_posterior(lat, x)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        hist = vi.train(x, num_epochs=5, lr_born_machine=0.005, verbose=True, true_posterior_for_tvd=post,
+                        optimizer_type=optimizer_type)
+    out = buf.getvalue()
+    assert "Precomputing score functions s_p(x,z)..." in out and "Score functions precomputed." in out
+    assert "Epoch 1/5 | KSD:" in out and "| LR:" in out and "| TVD:" in out and "Restoring best parameters" in out
+    K = os_.gram_closed_form(golden("sprinkler_w1.npz")["S"], 3)
+    tr = ok.EpochTrace("hardware_efficient", 3, 4, K, theta0, lr=0.005, num_epochs=5, clip=10.0,
+                       optimizer_type=optimizer_type)
+    for _ in range(5):
+        tr.step()
+    assert set(hist) == {'loss_ksd', 'tvd', 'grad_norm'} and len(hist['loss_ksd']) == 5
+    np.testing.assert_allclose(hist['loss_ksd'], tr.history['loss_ksd'], rtol=1e-6)
+    np.testing.assert_allclose([float(g) for g in hist['grad_norm']], tr.history['grad_norm'], rtol=1e-5)
+    np.testing.assert_allclose(vi.born_machine.theta.detach().cpu().numpy(), tr.history['theta'][-1], rtol=0, atol=2e-6)
+    assert all(0 <= t <= 1 for t in hist['tvd'])
+    assert vi.born_machine.theta.device.type == torch.device(device).type
+
+
+@pytest.mark.parametrize("ansatz,n,L,mode", [("hardware_efficient", 5, 2, "dense"), ("all_to_all", 5, 2, "kron"),
+                                              ("basic", 6, 2, "dense"), ("hardware_efficient", 8, 4, "kron")])
+def test_step_matches_oracle_synthetic(dev, ansatz, n, L, mode):
+    bn, lat, obs, x = synthetic_network(n, 0)
+    vi = make_vi(bn, lat, obs, n, L, ansatz, "cuda:0", seed=3, gram_mode=mode)
+    vi._prepare_stein(x)
+    loss, grad, q = vi.ksd_and_grad()
+    th = vi.born_machine.theta.detach().double().cpu().numpy()
+    q_o = oc.probs(ansatz, n, L, th)
+    K_o = os_.gram_closed_form(os_.score_matrix(bn, x, lat, obs), n)
+    np.testing.assert_allclose(q.cpu().numpy(), q_o, rtol=1e-10, atol=1e-14)
+    assert math.isclose(loss.item(), ok.ksd_loss(K_o, q_o), rel_tol=1e-9)
+    if n <= 6:
+        g_o = oc.paramshift_vjp(ansatz, n, L, th, ok.ksd_grad_q(K_o, q_o))
+        np.testing.assert_allclose(grad.cpu().numpy(), g_o, rtol=1e-7, atol=1e-9 * np.abs(g_o).max())
+
+
+def test_autograd_path_equals_fused_path(dev):
+    """`loss.backward()` through get_probabilities (the reference's route, ksd_vi_quantum.py:113-150)
+    gives the same gradient as the fused device step."""
+    bn = get_sprinkler_network(False)
+    lat, obs, x = ['C', 'S', 'R'], ['W'], {'W': 1}
+    vi = make_vi(bn, lat, obs, 3, 2, "hardware_efficient", "cuda:0", seed=5)
+    vi._prepare_stein(x)
+    loss_f, grad_f, _ = vi.ksd_and_grad()
+    bm = vi.born_machine
+    q = bm.get_probabilities().to(torch.float64)
+    assert q.requires_grad and q.dtype == torch.float64 and q.shape == (8,)
+    loss = torch.sqrt((q @ (vi._K @ q)).clamp(min=1e-12))
+    loss.backward()
+    assert bm.theta.grad.dtype == torch.float32
+    np.testing.assert_allclose(bm.theta.grad.cpu().numpy(), grad_f.cpu().numpy(), rtol=2e-6, atol=1e-6 * grad_f.abs().max().item())
+    assert math.isclose(loss.item(), loss_f.item(), rel_tol=1e-10)
+
+
+def test_born_machine_api(dev):
+    from tensornetworks_amd.quantum_born_machine import QuantumBornMachine
+    torch.manual_seed(0)
+    bm = QuantumBornMachine(4, ansatz_layers=2, ansatz_type="basic", init_method="random").to("cuda:0")
+    assert bm.num_ansatz_params == 16 and bm.theta.shape == (16,)
+    assert QuantumBornMachine(3, 2, init_method="zero").theta.abs().sum().item() == 0.0
+    assert QuantumBornMachine(3, 2, ansatz_type="all_to_all").num_ansatz_params == 18
+    d = bm.get_prob_dict()
+    assert list(d)[:3] == [(0, 0, 0, 0), (0, 0, 0, 1), (0, 0, 1, 0)] and abs(sum(d.values()) - 1) < 1e-12
+    q = np.array(list(d.values()))
+    np.testing.assert_allclose(q, oc.probs("basic", 4, 2, bm.theta.detach().double().cpu().numpy()), rtol=1e-10, atol=1e-14)
+    s = bm.sample(2000)
+    assert s.shape == (2000, 4) and s.dtype == torch.float32 and s.device.type == "cuda"
+    assert set(np.unique(s.cpu().numpy()).tolist()) <= {0.0, 1.0}
+    idx = (s.cpu().numpy() @ np.array([8, 4, 2, 1])).astype(int)
+    emp = np.bincount(idx, minlength=16) / 2000
+    assert np.abs(emp - q).max() < 0.06
+    z = torch.tensor([[0, 0, 0, 0], [1, 0, 1, 1]], dtype=torch.float32, device="cuda:0")
+    lq = bm.get_log_q_z_x(z)
+    np.testing.assert_allclose(lq.detach().cpu().numpy(), np.log(np.clip(q[[0, 11]], 1e-9, None)), rtol=1e-9)
+    with pytest.raises(ValueError):
+        bm.get_log_q_z_x(torch.tensor([[0, 2, 0, 0]], dtype=torch.float32))
+    assert bm.sample(0).shape == (0, 4)
+    assert bm.get_log_q_z_x(torch.empty(0, 4)).shape == (0,)
+
+
+def test_trainer_errors_and_lazy_attrs(dev):
+    bn = get_sprinkler_network(False)
+    vi = make_vi(bn, ['C', 'S', 'R'], ['W'], 3, 1, "hardware_efficient", "cuda:0")
+    with pytest.raises(ValueError, match="Keys in x_observation_dict"):
+        vi.train({'Q': 1}, 1, 0.01, verbose=False)
+    assert vi.num_possible_latent_states == 8 and len(vi.all_latent_states_tuples) == 8
+    assert vi.all_latent_states_tuples[5] == (1, 0, 1)
+    s = vi._get_precomputed_s_p((1, 0, 1), {'W': 1})
+    np.testing.assert_array_equal(s.cpu().numpy(), golden("sprinkler_w1.npz")["S"][5])
+    with contextlib.redirect_stdout(io.StringIO()):
+        hist = vi.train({'W': 1}, 2, 0.01, verbose=False, use_lr_scheduler=False, optimizer_type="other")
+    assert len(hist['tvd']) == 2 and all(np.isnan(hist['tvd']))
+
+
+def test_full_size_step_n16(dev):
+    """One KSD-gradient step at BASELINE config 3 (n=16, L=6), matrix-free and dense agree."""
+    n, L = 16, 6
+    bn, lat, obs, x = synthetic_network(n, 0)
+    vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=0, gram_mode="kron")
+    vi._prepare_stein(x)
+    loss_k, grad_k, q = vi.ksd_and_grad()
+    assert abs(q.sum().item() - 1) < 1e-12 and grad_k.shape == (288,) and torch.isfinite(grad_k).all()
+    vi.gram_mode = "dense"
+    vi._prepare_stein(x)
+    loss_d, grad_d, _ = vi.ksd_and_grad()
+    assert math.isclose(loss_k.item(), loss_d.item(), rel_tol=1e-9)
+    np.testing.assert_allclose(grad_k.cpu().numpy(), grad_d.cpu().numpy(), rtol=1e-7, atol=1e-9 * grad_d.abs().max().item())

@@ -1,0 +1,137 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/bornvi.h declares,
+the circuit planner (C++ host code) is correct against the oracle via the NumPy plan emulator,
+host helpers mirror the reference, and the product refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import circuit as oc, stein as os_
+import plan_emulator as pe
+from conftest import REPO, golden
+
+
+def test_library_exports_every_declared_symbol():
+    from tensornetworks_amd import _ext
+    lib = _ext.lib()
+    hdr = open(os.path.join(REPO, "include", "bornvi.h")).read()
+    declared = set(re.findall(r"\b(bornvi_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in bornvi.h but not exported"
+    assert declared == set(_ext.EXPORTED_SYMBOLS), declared ^ set(_ext.EXPORTED_SYMBOLS)
+    assert lib.bornvi_version() == 100
+    for ansatz, aid in _ext.ANSATZ_IDS.items():
+        for n, L in [(3, 4), (8, 4), (16, 6), (20, 8)]:
+            assert lib.bornvi_num_params(aid, n, L) == oc.num_params(ansatz, n, L)
+            assert lib.bornvi_num_gates(aid, n, L) == len(oc.gate_list(ansatz, n, L))
+    assert lib.bornvi_num_params(7, 3, 1) == -1 and lib.bornvi_num_gates(7, 3, 1) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu():
+    from tensornetworks_amd import _ext, backend
+    from tensornetworks_amd.quantum_born_machine import QuantumBornMachine
+    with pytest.raises(_ext.BornviError):
+        _ext.Handle(0)
+    with pytest.raises(_ext.BornviError):
+        backend.compute_device("cpu")
+    bm = QuantumBornMachine(3, 1)
+    with pytest.raises(_ext.BornviError, match="no CPU fallback"):
+        bm.get_probabilities()
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb", [(1, 1, 0), (2, 3, 0), (3, 4, 0), (5, 2, 0), (6, 3, 4), (7, 2, 5), (9, 2, 6),
+                                    (10, 2, 7), (11, 1, 13), (12, 1, 8)])
+def test_planner_against_oracle(ansatz, n, L, kb):
+    """The pass / stage / micro-op program emitted by the C++ planner, interpreted on NumPy exactly
+    as the HIP kernel interprets it, reproduces the oracle's q_theta."""
+    from tensornetworks_amd import _ext
+    W = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, L, kb)
+    rng = np.random.default_rng(n * 31 + L)
+    th = rng.uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
+    q = pe.run_plan(W, pe.fused_matrices(W, th))
+    np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
+    st = pe.plan_stats(W)
+    assert st["gates"] == len(oc.gate_list(ansatz, n, L)) and st["k"] == min(n, kb or 13)
+
+
+@pytest.mark.parametrize("n,kb", [(1, 0), (3, 0), (6, 4), (9, 5), (10, 7), (12, 13)])
+def test_kron_plan_against_oracle(n, kb):
+    """State-in / state-out program for K_base = M^{(x) n} (matrix-free Stein mat-vec)."""
+    from tensornetworks_amd import _ext
+    W = _ext.plan_words(-1, n, 0, kb)
+    a = np.exp(-1.0 / n)
+    M = np.array([[1, a], [a, 1]], dtype=np.complex128)
+    rng = np.random.default_rng(n)
+    v = rng.normal(size=2 ** n) + 1j * rng.normal(size=2 ** n)
+    out = pe.run_plan(W, [M], state_in=v)
+    ref = os_.kbase_apply(v.real, n, a) + 1j * os_.kbase_apply(v.imag, n, a)
+    np.testing.assert_allclose(out, ref, rtol=1e-13, atol=1e-13)
+
+
+def test_full_size_plans_are_well_formed():
+    from tensornetworks_amd import _ext
+    for ansatz_id in (0, 1, 2):
+        for n, L in [(16, 6), (20, 8)]:
+            W = _ext.plan_words(ansatz_id, n, L, 0)
+            st = pe.plan_stats(W)
+            assert st["k"] == 13 and 2 <= st["passes"] <= 3 * L + 2
+            assert int(W[8]) == len(W)
+    assert _ext.lib().bornvi_plan_describe(0, 31, 1, 0, None, 0) == -1       # n out of range
+    assert _ext.lib().bornvi_plan_describe(9, 4, 1, 0, None, 0) == -1        # unknown ansatz
+
+
+def test_utils_and_network_helpers():
+    from tensornetworks_amd import utils as u
+    from tensornetworks_amd.bayesian_network import (BayesianNetwork, get_sprinkler_network, pack_network,
+                                                      synthetic_network, joint_table)
+    assert u.generate_all_binary_outcomes(0) == [()]
+    assert u.generate_all_binary_outcomes(1) == [(0,), (1,)]
+    assert u.generate_all_binary_outcomes(3) == os_.generate_all_binary_outcomes(3)
+    assert all(u.outcome_index(z) == i for i, z in enumerate(u.generate_all_binary_outcomes(5)))
+    p1 = {'00': 0.25, '01': 0.25, '10': 0.25, '11': 0.25}
+    p2 = {'00': 0.5, '01': 0.1, '10': 0.1, '11': 0.3}
+    assert abs(u.calculate_tvd(p1, p2) - 0.3) < 1e-15                                  # utils.py:96-102
+    assert abs(u.calculate_tvd(np.array([.25] * 4), np.array([.5, .1, .1, .3])) - 0.3) < 1e-15
+    with pytest.raises(ValueError):
+        u.calculate_tvd(np.zeros(3), np.zeros(4))
+    with pytest.raises(TypeError):
+        u.calculate_tvd(p1, np.zeros(4))
+    bn = get_sprinkler_network(False)
+    assert bn.nodes == ['C', 'S', 'R', 'W'] and bn.parents['W'] == ['S', 'R']
+    assert abs(bn.get_joint_probability((1, 0, 1, 1)) - 0.5 * 0.9 * 0.8 * 0.9) < 1e-16
+    with pytest.raises(ValueError):
+        bn.add_node('C', cpt={})
+    with pytest.raises(ValueError):
+        BayesianNetwork().add_node('X', cpt={}, parent_names=['nope'])
+    with pytest.raises(ValueError):
+        bn.get_joint_probability((1, 0))
+    g = golden("sprinkler_w1.npz")
+    np.testing.assert_array_equal(joint_table(bn, ['C', 'S', 'R'], {'W': 1}), g["pxz"])
+    pk = pack_network(bn, ['C', 'S', 'R'], {'W': 1})
+    for k in pk:
+        np.testing.assert_array_equal(pk[k], g["pack_" + k])
+    sb, lat, obs, x = synthetic_network(6, 0)
+    assert lat == [f"Z{i}" for i in range(6)] and obs == ["X"] and x == {"X": 1}
+    assert sb.parents["Z4"] == ["Z3", "Z2"] and sb.parents["Z5"] == ["Z4"] and sb.parents["X"] == ["Z4", "Z5"]
+    sb2, *_ = synthetic_network(6, 0)
+    assert sb.cpts == sb2.cpts                                                          # seeded
+    hidden = pack_network(bn, ['C', 'R'], {'W': 0})
+    assert hidden["role"].tolist() == [0, -3, 1, -1]
+
+
+def test_shard_ranges_cover_all_parameters():
+    from tensornetworks_amd.paramshift_shard import shard_range
+    for P in (0, 1, 7, 36, 96, 288, 480):
+        for W in (1, 2, 3, 4, 8):
+            got = []
+            for r in range(W):
+                lo, hi = shard_range(P, r, W)
+                assert 0 <= lo <= hi <= P
+                got += list(range(lo, hi))
+            assert got == list(range(P))
+    assert shard_range(288, 3, 8) == (108, 144) and shard_range(480, 7, 8) == (420, 480)
