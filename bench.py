@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""KSD-gradient steps/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE config 3 -- quantum Born machine n = 16 qubits, L = 6 layers,
+`hardware_efficient` ansatz (P = 288, 577 circuits of 421 gates per step), synthetic 17-node
+Bayesian network (seed 0), dense 2^16 x 2^16 fp64 Stein Gram (32 GiB),
+Adam + cosine schedule + clip as run_sprinkler_quantum_ksd.py:35-43.
+
+One step = one epoch body of ksd_vi_quantum.py:110-161 with TVD tracking off: base circuit -> q,
+KSD = sqrt(clamp(q^T K_p q)), dL/dq, 2P parameter-shift circuits -> grad, clip, Adam, scheduler.
+S and K_p are built once before the timed region (they do not depend on theta).
+
+N > 1 (strong scaling: the same step, split): the 2P shifted circuits and the rows of K_p are
+sharded over the ranks; two small all-gathers per step (K q rows, gradient scalars) over RCCL.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (n, layers, ansatz, gram_mode)
+    "n16_L6_dense": (16, 6, "hardware_efficient", "dense"),
+    "n16_L6_kron": (16, 6, "hardware_efficient", "kron"),
+    "n8_L4_dense": (8, 4, "hardware_efficient", "dense"),
+    "n20_L8_kron": (20, 8, "hardware_efficient", "kron"),
+    "n12_L4_dense": (12, 4, "hardware_efficient", "dense"),
+}
+
+
+def mean_ms(pairs):
+    return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
+
+
+def gate_apply_microbench(dev, n=16, total_bytes=4 << 30, reps=20, warm=5):
+    """Un-fused gate kernels on a batch of states >> Infinity Cache: algorithmic == real traffic,
+    32 * 2^n bytes per gate per state."""
+    from tensornetworks_amd import backend
+    from oracle import circuit as oc
+    B = total_bytes // (16 << n)
+    st = torch.randn((B, 2 << n), dtype=torch.float64, device=dev).view(torch.complex128).view(B, 1 << n)
+    st /= st.abs().pow(2).sum(1, keepdim=True).sqrt()
+    U = oc.matrix_1q("RY", 0.3)
+    out = {"n": n, "batch": int(B), "bytes_per_launch": int(32 * B << n), "gbs": {}}
+    cases = [("ry_wire0", lambda: backend.gate1q_apply(st, n, 0, U)),
+             (f"ry_wire{n // 2}", lambda: backend.gate1q_apply(st, n, n // 2, U)),
+             (f"ry_wire{n - 1}", lambda: backend.gate1q_apply(st, n, n - 1, U)),
+             ("cnot_0_1", lambda: backend.cnot_apply(st, n, 0, 1))]
+    for name, fn in cases:
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize(dev)
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        out["gbs"][name] = round(out["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+    vals = [v for k, v in out["gbs"].items() if k.startswith("ry")]
+    out["ry_mean_gbs"] = round(float(np.mean(vals)), 1)
+    out["frac_of_hbm_peak"] = round(out["ry_mean_gbs"] / HBM_PEAK_GBS, 4)
+    del st
+    return out
+
+
+def cpu_baseline(n, layers, ansatz, S_host, theta64, total_circuits):
+    """The oracle's C port (oracle/cpu_port.c, OpenMP) on the host cores, on a bounded sample of the
+    same step, extrapolated linearly in circuits and Gram rows.  A reported baseline, not a target."""
+    from oracle import cpu_port as cp
+    if not cp.available():
+        return None
+    T = cp.max_threads()
+    P = theta64.size
+    npar = max(1, min(P, 2 * T))
+    t0 = time.perf_counter()
+    probs, used = cp.paramshift_probs(ansatz, n, layers, theta64, 0, npar, include_base=True)
+    t_circ = time.perf_counter() - t0
+    n_circ = probs.shape[0]
+    rows = min(1 << n, 1024)
+    K_rows = cp.gram_rows(S_host, n, 1.0, 0, rows)            # building K is outside the step
+    q = np.ascontiguousarray(probs[0])
+    cp.gemv_rows(K_rows, n, 0, rows, q)                         # warm
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        cp.gemv_rows(K_rows, n, 0, rows, q)
+    t_gemv = (time.perf_counter() - t0) / reps
+    step_s = t_circ * total_circuits / n_circ + t_gemv * (1 << n) / rows
+    return {"value": round(1.0 / step_s, 6), "unit": "steps/s", "cores": int(used), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{n_circ} of {total_circuits} circuits ({t_circ:.2f} s) + {rows} of {1 << n} Gram rows GEMV "
+                      f"({t_gemv * 1e3:.1f} ms), oracle/cpu_port.c with OpenMP, extrapolated linearly",
+            "est_step_seconds": round(step_s, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="n16_L6_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gate-bench", action="store_true")
+    ap.add_argument("--tile-bits", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from tensornetworks_amd import backend, _ext
+    from tensornetworks_amd.bayesian_network import synthetic_network
+    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+
+    n, layers, ansatz, gram_mode = WORKLOADS[args.workload]
+    if args.tile_bits:
+        backend.set_option(dev, "tile_bits", args.tile_bits)
+    bn, lat, obs, x = synthetic_network(n, seed=0)
+    torch.manual_seed(0)
+    vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,
+                                 qbm_ansatz_type=ansatz, pytorch_device=str(dev), gram_mode=gram_mode)
+    g = torch.Generator().manual_seed(0)
+    P = vi.born_machine.num_ansatz_params
+    with torch.no_grad():     # theta0 = 0.1 * randn(P) float32, `small_random` (quantum_born_machine.py:43-45)
+        vi.born_machine.theta.copy_((0.1 * torch.randn(P, generator=g, dtype=torch.float32)).to(dev))
+    theta0 = vi.born_machine.theta.detach().double().cpu().numpy()
+
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    vi._prepare_stein(x)
+    torch.cuda.synchronize(dev)
+    precompute_s = time.perf_counter() - t0
+
+    total_steps = args.steps + args.warmup
+    params, opt, sched = vi.make_optimizer(0.005, total_steps, True, "adam", (0.9, 0.999))
+    clip = 10.0
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(vi.training_step(params, opt, sched, clip)[0])
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    vi.timers = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(vi.training_step(params, opt, sched, clip)[0])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timers = vi.timers
+    vi.timers = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)
+        n_passes, n_gates = int(plan[3]), int(plan[11])
+        lo, hi = (0, P) if world == 1 else (0, -(-P // world))
+        circuits_rank = 1 + 2 * (hi - lo)
+        circ_ms, stein_ms, fin_ms = mean_ms(timers.get("circuits")), mean_ms(timers.get("stein")), mean_ms(timers.get("finish"))
+        N = 1 << n
+        # algorithmic bytes: 32 * 2^n per gate per state; dense contraction 8 * 4^n
+        circ_bytes = 32.0 * N * n_gates * circuits_rank
+        rows_rank = -(-N // world)
+        stein_bytes = 8.0 * N * rows_rank if gram_mode == "dense" else 16.0 * N * n * (n + 1)
+        kern = {
+            "circuit_pass_kernel": {"bound": "hbm", "launches_per_step": n_passes,
+                                    "achieved": round(circ_bytes / (circ_ms * 1e-3) / 1e9, 1) if circ_ms else None,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_ms, 4),
+                                    "avg_launch_ms": round(circ_ms / n_passes, 4),
+                                    "algorithmic_bytes_per_step": circ_bytes, "traffic": None,
+                                    "note": "gate-apply accounting: un-fused bytes; passes keep the state in LDS, so "
+                                            "achieved may exceed the HBM peak (real traffic: profiles/)"},
+            ("quadform_kernel" if gram_mode == "dense" else "kron_matvec"): {
+                "bound": "hbm", "launches_per_step": 1,
+                "achieved": round(stein_bytes / (stein_ms * 1e-3) / 1e9, 1) if stein_ms else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(stein_ms, 4),
+                "avg_launch_ms": round(stein_ms, 4), "algorithmic_bytes_per_step": stein_bytes, "traffic": None},
+        }
+        for v in kern.values():
+            v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
+        dom_name = max(kern, key=lambda k_: kern[k_]["ms_per_step"])
+        roof = dict(kern[dom_name])
+        roof["kernel"] = dom_name
+        value = args.steps / elapsed
+        rec = {
+            "metric": "ksd_gradient_steps_per_sec", "value": round(value, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "n_qubits": n, "layers": layers, "ansatz": ansatz,
+                       "params": P, "circuits_per_step": 1 + 2 * P, "gates_per_circuit": n_gates,
+                       "gram": gram_mode, "bayesian_network": f"synthetic n={n} seed=0 (SURVEY 8d)",
+                       "optimizer": "adam lr=0.005 cosine clip=10", "parallelism": f"paramshift+gram-rows shard x{world}",
+                       "tile_bits": int(plan[2]), "passes": n_passes},
+            "roofline": roof, "kernels": kern,
+            "phase_ms": {"circuits": round(circ_ms, 4), "stein": round(stein_ms, 4), "finish": round(fin_ms, 4)},
+            "precompute_seconds": round(precompute_s, 3),
+            "loss_first_last": [losses[0], losses[-1]],
+        }
+        if world == 1 and not args.no_gate_bench:
+            vi._K = None
+            torch.cuda.empty_cache()
+            rec["gate_apply"] = gate_apply_microbench(dev, n=min(n, 16) if n >= 10 else 16)
+        if world == 1 and not args.no_cpu_baseline:
+            S_host = vi._S.cpu().numpy()
+            rec["cpu_baseline"] = cpu_baseline(n, layers, ansatz, S_host, theta0, 1 + 2 * P)
+            if rec["cpu_baseline"]:
+                rec["gpu_over_cpu"] = round(value / rec["cpu_baseline"]["value"], 1)
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,12 @@ int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, dou
 int bornvi_stein_gram_build(bornvi_handle h, int n, double length_scale, const double* S,
                             double* K, bornvi_stream stream);
 
+/* Row block [row_begin, row_end) of K_p, K_rows dev [row_end - row_begin, 2^n]: lets each GPU of a
+ * node hold 1/W of the Gram matrix (multi-GPU row shard of the quadratic form). */
+int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, const double* S,
+                                 long long row_begin, long long row_end, double* K_rows,
+                                 bornvi_stream stream);
+
 /* k_p(z_i, z_j | x) for M explicit pairs -- the batched form of ONE call of
  * stein_utils.get_stein_kernel_kp_value (:138-197): zi, zj dev int64 [M] outcome indices,
  * si, sj dev [M, n] the score rows sp_at_z1 / sp_at_z2 supplied by the caller, out dev [M]. */
@@ -148,6 +154,14 @@ size_t bornvi_stein_quadform_workspace_bytes(bornvi_handle h, int n, int B);
 int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B,
                           double* ksd2, double* Y, void* workspace, size_t workspace_bytes,
                           bornvi_stream stream);
+
+/* Row-sharded form: K_rows holds rows [row_begin, row_end); q dev [2^n] (full);
+ * y_rows dev [row_end - row_begin] = those rows of K q (or NULL); ksd2_partial dev [1] =
+ * sum over them of q_i y_i.  Workspace as bornvi_stein_quadform. */
+int bornvi_stein_quadform_rows(bornvi_handle h, int n, const double* K_rows, long long row_begin,
+                               long long row_end, const double* q, double* y_rows,
+                               double* ksd2_partial, void* workspace, size_t workspace_bytes,
+                               bornvi_stream stream);
 
 /* Matrix-free y = K_p q via the Kronecker structure of K_p (needed where the dense Gram does
  * not fit: n = 20 would be 8 TiB).  q, y dev [2^n]; ksd2 dev [1]. */

@@ -55,6 +55,10 @@ _PROTOS = {
     "bornvi_born_probs": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_score_from_cpts": (C.c_int, [C.c_void_p, C.POINTER(BnDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_stein_gram_build": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bornvi_stein_gram_build_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_longlong, C.c_longlong,
+                                               C.c_void_p, C.c_void_p]),
+    "bornvi_stein_quadform_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_stein_kp_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_longlong, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_stein_quadform_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -172,13 +172,31 @@ def score_from_packed(packed, n, dev):
     return S, pxz
 
 
-def stein_gram(S, n, length_scale=1.0):
+def stein_gram(S, n, length_scale=1.0, rows=None):
+    """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard)."""
     dev = S.device
     h = _ext.handle_for(dev)
     _chk(S, torch.float64, dev, "S")
-    K = torch.empty((1 << n, 1 << n), dtype=torch.float64, device=dev)
-    h.call("bornvi_stein_gram_build", n, float(length_scale), _ptr(S), _ptr(K), _ext.stream_ptr(dev))
+    r0, r1 = (0, 1 << n) if rows is None else (int(rows[0]), int(rows[1]))
+    K = torch.empty((r1 - r0, 1 << n), dtype=torch.float64, device=dev)
+    h.call("bornvi_stein_gram_build_rows", n, float(length_scale), _ptr(S), r0, r1, _ptr(K), _ext.stream_ptr(dev))
     return K
+
+
+def stein_quadform_rows(K_rows, r0, r1, q, n, out=None):
+    """K_rows = rows [r0, r1) of K_p; returns a [r1 - r0 + 1] vector: those rows of K q followed by
+    the partial sum over them of q_i y_i (the message one rank contributes to the all-gather)."""
+    dev = K_rows.device
+    h = _ext.handle_for(dev)
+    _chk(K_rows, torch.float64, dev, "K_rows")
+    _chk(q, torch.float64, dev, "q")
+    nr = r1 - r0
+    if out is None:
+        out = torch.empty(nr + 1, dtype=torch.float64, device=dev)
+    ws = _ws(dev, h.size("bornvi_stein_quadform_workspace_bytes", n, 1), "qf")
+    h.call("bornvi_stein_quadform_rows", n, _ptr(K_rows), int(r0), int(r1), _ptr(q), _ptr(out),
+           C.c_void_p(out.data_ptr() + 8 * nr), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
+    return out
 
 
 def stein_kp_pairs(n, length_scale, zi, zj, si, sj):

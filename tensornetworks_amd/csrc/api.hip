@@ -97,7 +97,8 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
                   int shift_mode, int p_begin, int include_base, double* probs, void* ws, size_t ws_bytes,
                   hipStream_t st) {
   if (!h) return BORNVI_ERR_INVALID;
-  if (batch < 0 || (!thetas) || (!probs && batch > 0)) return fail(h, BORNVI_ERR_INVALID, "null pointer or negative batch");
+  if (batch < 0 || (!thetas && num_params(ansatz, n, layers) > 0) || (!probs && batch > 0))
+    return fail(h, BORNVI_ERR_INVALID, "null pointer or negative batch");
   if (batch == 0) return BORNVI_OK;
   DevPlan* dp = nullptr;
   int rc = get_plan(h, ansatz, n, layers, &dp);
@@ -280,14 +281,21 @@ int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, dou
   return BORNVI_OK;
 }
 
-int bornvi_stein_gram_build(bornvi_handle h, int n, double length_scale, const double* S, double* K, bornvi_stream stream) {
+int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,
+                                 long long row_end, double* K_rows, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
-  if (!S || !K) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!S || (!K_rows && row_end > row_begin)) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17 (8 * 4^n bytes)");
   if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
+  if (row_begin < 0 || row_end < row_begin || row_end > (1ll << n)) return fail(h, BORNVI_ERR_INVALID, "row range out of bounds");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_gram_build(n, length_scale, S, K, (hipStream_t)stream));
+  HIPCHK(h, launch_gram_build(n, length_scale, S, K_rows, row_begin, row_end, (hipStream_t)stream));
   return BORNVI_OK;
+}
+
+int bornvi_stein_gram_build(bornvi_handle h, int n, double length_scale, const double* S, double* K, bornvi_stream stream) {
+  if (n < 0 || n > 40) return h ? fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17 (8 * 4^n bytes)") : BORNVI_ERR_INVALID;
+  return bornvi_stein_gram_build_rows(h, n, length_scale, S, 0, 1ll << n, K, stream);
 }
 
 int bornvi_stein_kp_pairs(bornvi_handle h, int n, double length_scale, long long M, const long long* zi,
@@ -303,7 +311,21 @@ int bornvi_stein_kp_pairs(bornvi_handle h, int n, double length_scale, long long
 size_t bornvi_stein_quadform_workspace_bytes(bornvi_handle h, int n, int B) {
   (void)h; (void)B;
   if (n < 1 || n > 30) return 0;
-  return align_up(quadform_partials(n) * sizeof(double), 256);
+  return align_up(quadform_partials(1ll << n) * sizeof(double), 256);
+}
+
+int bornvi_stein_quadform_rows(bornvi_handle h, int n, const double* K_rows, long long row_begin, long long row_end,
+                               const double* q, double* y_rows, double* ksd2_partial, void* workspace,
+                               size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!q || !ksd2_partial || (!K_rows && row_end > row_begin)) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  if (row_begin < 0 || row_end < row_begin || row_end > (1ll << n)) return fail(h, BORNVI_ERR_INVALID, "row range out of bounds");
+  if (!workspace || workspace_bytes < bornvi_stein_quadform_workspace_bytes(h, n, 1))
+    return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_quadform(n, K_rows, row_begin, row_end, q, y_rows, ksd2_partial, (double*)workspace, (hipStream_t)stream));
+  return BORNVI_OK;
 }
 
 int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B, double* ksd2, double* Y,
@@ -316,7 +338,7 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
   HIPCHK(h, hipSetDevice(h->device));
   const long long N = 1ll << n;
   for (int b = 0; b < B; ++b)
-    HIPCHK(h, launch_quadform(n, K, Q + b * N, Y ? Y + b * N : nullptr, ksd2 + b, (double*)workspace, nullptr, (hipStream_t)stream));
+    HIPCHK(h, launch_quadform(n, K, 0, N, Q + b * N, Y ? Y + b * N : nullptr, ksd2 + b, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;
 }
 

@@ -12,11 +12,9 @@
 
 namespace bornvi {
 
-// LDS index swizzle: xor-fold the upper nibbles into the low nibble.  Linear over GF(2)
-// (swz(a ^ b) == swz(a) ^ swz(b)), its own inverse, keeps bits >= 4.  With it a 16-lane
-// ds_read_b128 group is conflict-free whenever its lane bits land on LDS bit positions with
-// distinct residues mod 4 (the planner's order_for_banks), including register wires on bits 0-3.
-__device__ __forceinline__ uint32_t swz(uint32_t l) { return l ^ (((l >> 4) ^ (l >> 8) ^ (l >> 12)) & 15u); }
+// LDS index swizzle `lds_swizzle` (plan.hpp): with it a 16-lane ds_read_b128 group is conflict-free
+// whenever its lane bits land on LDS bit positions with distinct residues mod 4 (the planner's
+// order_for_banks), including register wires on bits 0-3.
 
 // ------------------------------------------------------------------------------------------------
 // fused one-qubit matrices: U = G_{ne-1} ... G_1 G_0 (G_0 applied first), PennyLane conventions
@@ -104,27 +102,20 @@ __device__ __forceinline__ void op_u1(double (&ar)[16], double (&ai)[16], const 
   }
 }
 
-template <int C, int T>
-__device__ __forceinline__ void op_cx_rr(double (&ar)[16], double (&ai)[16]) {
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (!(j & (1 << C)) || (j & (1 << T))) continue;
-    const int j1 = j | (1 << T);
-    const double tr = ar[j], ti = ai[j];
-    ar[j] = ar[j1]; ai[j] = ai[j1];
-    ar[j1] = tr; ai[j1] = ti;
+// product of CZ gates = (-1)^{q(x)}: q(e ^ o_j) = q(e) ^ q(o_j) ^ parity(e & m_j) for the 16 slot offsets o_j
+__device__ __forceinline__ void apply_sign(const uint32_t* __restrict__ Q, uint32_t e, int n, double (&ar)[16],
+                                           double (&ai)[16]) {
+  uint32_t acc = 0;
+  for (int q = 0; q < n; ++q) {
+    const uint32_t row = Q[q];
+    acc ^= ((e >> q) & 1u) & (uint32_t)__popc(e & row);
   }
-}
-
-template <int T>
-__device__ __forceinline__ void op_cx_ar(double (&ar)[16], double (&ai)[16], bool c) {
+  const uint32_t qbits = Q[48] ^ (0u - (acc & 1u));
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    if (j & (1 << T)) continue;
-    const int j1 = j | (1 << T);
-    const double a0r = ar[j], a0i = ai[j], a1r = ar[j1], a1i = ai[j1];
-    ar[j] = c ? a1r : a0r; ai[j] = c ? a1i : a0i;
-    ar[j1] = c ? a0r : a1r; ai[j1] = c ? a0i : a1i;
+    const uint32_t sgn = ((qbits >> j) ^ (uint32_t)__popc(e & Q[32 + j])) & 1u;
+    ar[j] = sgn ? -ar[j] : ar[j];
+    ai[j] = sgn ? -ai[j] : ai[j];
   }
 }
 
@@ -167,94 +158,69 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
       uint32_t itp = 0;
       for (int j = kt; j < k; ++j) itp |= (((uint32_t)i >> (j - kt)) & 1u) << P[PW_IN_PHYS + j];
       const uint32_t u = t | ((uint32_t)i << kt);
-      tile[swz(u)] = src[thr | itp];
+      tile[lds_swizzle(u)] = src[thr | itp];
     }
   }
   __syncthreads();
 
   // ---- stages: 2^r amplitudes per thread in registers, one LDS round trip each -----------------------
+  // Fixed form (plan.hpp): read with the phase-0 CNOT permutation folded into the address, optional sign,
+  // one fused U per register wire (all four matrices fetched up front by scalar loads), optional sign on
+  // the permuted index, write with the phase-3 CNOT permutation folded into the address.
   const uint32_t* __restrict__ S = P + PW_STAGES;
   for (int s = 0; s < nstages; ++s) {
     const uint32_t hdr = S[0];
     const int r = (int)(hdr & 0xffu);
-    const int nops = (int)((hdr >> 8) & 0xffu);
+    const uint32_t sflags = (hdr >> 8) & 0xffu;
     const uint32_t nwords = hdr >> 16;
     if (t < (1u << (k - r))) {
       const uint32_t rho = S[1];
+      const uint32_t f01 = S[6], f23 = S[7];
+      const uint32_t fi[4] = {f01 & 0xffffu, f01 >> 16, f23 & 0xffffu, f23 >> 16};
+      double U[4][8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double* __restrict__ Ug = gates + b * gate_stride + (size_t)(fi[i] == 0xffffu ? 0u : fi[i]) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) U[i][q] = Ug[q];
+      }
       uint32_t base = 0;
       for (int j = 0; j < k - r; ++j) base |= ((t >> j) & 1u) << ((S[2 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
-      const uint32_t pb = swz(base);
+      const uint32_t pb = lds_swizzle(base);
       const uint32_t e = base | (g << k);  // extended index: LDS bits then workgroup bits
-      uint32_t sr[4];
+      uint32_t lflip = 0, sflip = 0, e2 = e;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sr[i] = (i < r) ? swz(1u << ((rho >> (8 * i)) & 0xffu)) : 0u;
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t rp = (rho >> (8 * i)) & 0xffu;
+        const uint32_t sri = (i < r) ? lds_swizzle(1u << rp) : 0u;
+        const uint32_t bpre = S[8 + i], bpost = S[12 + i];
+        if (bpre) lflip ^= (__popc(e & bpre) & 1) ? sri : 0u;
+        if (bpost) {
+          const uint32_t bit = (uint32_t)__popc(e & bpost) & 1u;
+          sflip ^= bit ? sri : 0u;
+          e2 |= bit << rp;
+        }
+      }
       const int nreg = 1 << r;
+      const uint32_t rbase = pb ^ lflip, wbase = pb ^ sflip;
       double ar[16], ai[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const uint32_t off = ((j & 1) ? sr[0] : 0u) ^ ((j & 2) ? sr[1] : 0u) ^ ((j & 4) ? sr[2] : 0u) ^ ((j & 8) ? sr[3] : 0u);
-        if (j < nreg) { const double2 v = tile[pb ^ off]; ar[j] = v.x; ai[j] = v.y; }
+        const uint32_t off = (S[16 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
+        if (j < nreg) { const double2 v = tile[rbase ^ off]; ar[j] = v.x; ai[j] = v.y; }
         else { ar[j] = 0.0; ai[j] = 0.0; }
       }
-      const uint32_t* __restrict__ op = S + STAGE_HDR_WORDS;
-      for (int o = 0; o < nops; ++o) {
-        const uint32_t w = *op++;
-        const uint32_t kind = w & 15u, a = (w >> 4) & 63u, bb = (w >> 10) & 63u, idx = w >> 16;
-        if (kind == OP_U1) {
-          const double* __restrict__ Ug = gates + b * gate_stride + (size_t)idx * 8;
-          double U[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) U[i] = Ug[i];
-          switch (a) {
-            case 0: op_u1<0>(ar, ai, U); break;
-            case 1: op_u1<1>(ar, ai, U); break;
-            case 2: op_u1<2>(ar, ai, U); break;
-            default: op_u1<3>(ar, ai, U); break;
-          }
-        } else if (kind == OP_CX_RR) {
-          switch (a * 4 + bb) {
-            case 1: op_cx_rr<0, 1>(ar, ai); break;
-            case 2: op_cx_rr<0, 2>(ar, ai); break;
-            case 3: op_cx_rr<0, 3>(ar, ai); break;
-            case 4: op_cx_rr<1, 0>(ar, ai); break;
-            case 6: op_cx_rr<1, 2>(ar, ai); break;
-            case 7: op_cx_rr<1, 3>(ar, ai); break;
-            case 8: op_cx_rr<2, 0>(ar, ai); break;
-            case 9: op_cx_rr<2, 1>(ar, ai); break;
-            case 11: op_cx_rr<2, 3>(ar, ai); break;
-            case 12: op_cx_rr<3, 0>(ar, ai); break;
-            case 13: op_cx_rr<3, 1>(ar, ai); break;
-            case 14: op_cx_rr<3, 2>(ar, ai); break;
-            default: break;
-          }
-        } else if (kind == OP_CX_AR) {
-          const bool c = (e >> a) & 1u;
-          switch (bb) {
-            case 0: op_cx_ar<0>(ar, ai, c); break;
-            case 1: op_cx_ar<1>(ar, ai, c); break;
-            case 2: op_cx_ar<2>(ar, ai, c); break;
-            default: op_cx_ar<3>(ar, ai, c); break;
-          }
-        } else {  // OP_SIGNQ: product of CZ gates = (-1)^{q(x)}, q a quadratic form over index bits
-          uint32_t acc = 0;
-          for (int q = 0; q < n; ++q) {
-            const uint32_t row = op[q];
-            acc ^= ((e >> q) & 1u) & (uint32_t)__popc(e & row);
-          }
-          const uint32_t qbits = op[48] ^ (0u - (acc & 1u));
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const uint32_t sgn = ((qbits >> j) ^ (uint32_t)__popc(e & op[32 + j])) & 1u;
-            ar[j] = sgn ? -ar[j] : ar[j];
-            ai[j] = sgn ? -ai[j] : ai[j];
-          }
-          op += SIGNQ_WORDS;
-        }
-      }
+      const uint32_t* __restrict__ Q = S + STAGE_HDR_WORDS;
+      if (sflags & STAGE_SIGN_PRE) { apply_sign(Q, e, n, ar, ai); Q += SIGNQ_WORDS; }
+      if (fi[0] != 0xffffu) op_u1<0>(ar, ai, U[0]);
+      if (fi[1] != 0xffffu) op_u1<1>(ar, ai, U[1]);
+      if (fi[2] != 0xffffu) op_u1<2>(ar, ai, U[2]);
+      if (fi[3] != 0xffffu) op_u1<3>(ar, ai, U[3]);
+      if (sflags & STAGE_SIGN_POST) apply_sign(Q, e2, n, ar, ai);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const uint32_t off = ((j & 1) ? sr[0] : 0u) ^ ((j & 2) ? sr[1] : 0u) ^ ((j & 4) ? sr[2] : 0u) ^ ((j & 8) ? sr[3] : 0u);
-        if (j < nreg) tile[pb ^ off] = make_double2(ar[j], ai[j]);
+        const uint32_t off = (S[24 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
+        if (j < nreg) tile[wbase ^ off] = make_double2(ar[j], ai[j]);
       }
     }
     __syncthreads();
@@ -278,7 +244,7 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
         it_l |= bit << P[PW_OUT_LDS + j];
         it_p |= bit << P[PW_OUT_PHYS + j];
       }
-      const double2 v = tile[swz(thr_l | it_l)];
+      const double2 v = tile[lds_swizzle(thr_l | it_l)];
       if (fin) pdst[thr_p | it_p] = v.x * v.x + v.y * v.y;
       else dst[thr_p | it_p] = v;
     }

@@ -78,7 +78,8 @@ struct PowTable { double v[33]; };
 
 template <int NB>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ S, double* __restrict__ K,
-                                                   PowTable apow, double c_same, double dc) {
+                                                   PowTable apow, double c_same, double dc,
+                                                   long long row_begin, long long row_end) {
   const long long N = 1ll << NB;
   const long long j0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (j0 >= N) return;
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ S,
       RTj[c] += Tj[c][b];
     }
   }
-  const long long i_begin = (long long)blockIdx.y * GRAM_ROWS;
-  const long long i_end = (i_begin + GRAM_ROWS < N) ? i_begin + GRAM_ROWS : N;
+  const long long i_begin = row_begin + (long long)blockIdx.y * GRAM_ROWS;
+  const long long i_end = (i_begin + GRAM_ROWS < row_end) ? i_begin + GRAM_ROWS : row_end;
   for (long long i = i_begin; i < i_end; ++i) {
     double Si[NB], Ti[NB], RTi = 0.0;
 #pragma unroll
@@ -112,19 +113,22 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ S,
       }
       out[c] = apow.v[__popc(x)] * (dot - c_same * (RTi + RTj[c]) - dc * ms);
     }
-    *reinterpret_cast<double2*>(K + i * N + j0) = make_double2(out[0], out[1]);
+    *reinterpret_cast<double2*>(K + (i - row_begin) * N + j0) = make_double2(out[0], out[1]);
   }
 }
 
 template <int NB>
-static hipError_t launch_gram_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc, hipStream_t st) {
+static hipError_t launch_gram_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc,
+                                 long long row_begin, long long row_end, hipStream_t st) {
   const long long N = 1ll << NB;
-  dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)((N + GRAM_ROWS - 1) / GRAM_ROWS));
-  gram_kernel<NB><<<grid, 256, 0, st>>>(S, K, apow, c_same, dc);
+  if (row_end <= row_begin) return hipSuccess;
+  dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)((row_end - row_begin + GRAM_ROWS - 1) / GRAM_ROWS));
+  gram_kernel<NB><<<grid, 256, 0, st>>>(S, K, apow, c_same, dc, row_begin, row_end);
   return hipGetLastError();
 }
 
-hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, hipStream_t st) {
+hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, long long row_begin,
+                             long long row_end, hipStream_t st) {
   PowTable apow;
   const double denom = (double)n * length_scale;
   for (int d = 0; d <= 32; ++d) apow.v[d] = std::exp(-(double)d / denom);  // stein_utils.py:55
@@ -132,7 +136,7 @@ hipError_t launch_gram_build(int n, double length_scale, const double* S, double
   const double c_same = 1.0 - a, c_diff = 1.0 - 1.0 / a;
   const double dc = c_diff - c_same;
   switch (n) {
-#define BORNVI_GRAM_CASE(NB) case NB: return launch_gram_nb<NB>(S, K, apow, c_same, dc, st);
+#define BORNVI_GRAM_CASE(NB) case NB: return launch_gram_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, st);
     BORNVI_GRAM_CASE(1) BORNVI_GRAM_CASE(2) BORNVI_GRAM_CASE(3) BORNVI_GRAM_CASE(4) BORNVI_GRAM_CASE(5)
     BORNVI_GRAM_CASE(6) BORNVI_GRAM_CASE(7) BORNVI_GRAM_CASE(8) BORNVI_GRAM_CASE(9) BORNVI_GRAM_CASE(10)
     BORNVI_GRAM_CASE(11) BORNVI_GRAM_CASE(12) BORNVI_GRAM_CASE(13) BORNVI_GRAM_CASE(14) BORNVI_GRAM_CASE(15)
@@ -189,16 +193,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 __global__ __launch_bounds__(64 * QF_WAVES) void quadform_kernel(const double* __restrict__ K, const double* __restrict__ q,
-                                                                 double* __restrict__ y, double* __restrict__ partials, long long N) {
+                                                                 double* __restrict__ y, double* __restrict__ partials, long long N,
+                                                                 long long row_begin, long long NR) {
   __shared__ double wpart[QF_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long row0 = ((long long)blockIdx.x * QF_WAVES + wave) * QF_ROWS;
   double acc[QF_ROWS];
 #pragma unroll
   for (int r = 0; r < QF_ROWS; ++r) acc[r] = 0.0;
-  if (row0 < N) {
+  if (row0 < NR) {
     const double* __restrict__ Kr = K + row0 * N;
-    if (row0 + QF_ROWS <= N) {
+    if (row0 + QF_ROWS <= NR) {
 #pragma unroll 4
       for (long long c = lane * 2; c < N; c += 128) {
         const double2 q2 = *reinterpret_cast<const double2*>(q + c);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64 * QF_WAVES) void quadform_kernel(const double* _
       for (long long c = lane * 2; c < N; c += 128) {
         const double2 q2 = *reinterpret_cast<const double2*>(q + c);
         for (int r = 0; r < QF_ROWS; ++r)
-          if (row0 + r < N) {
+          if (row0 + r < NR) {
             const double* p = Kr + r * N + c;
             acc[r] = fma(p[0], q2.x, fma(p[1], q2.y, acc[r]));
           }
@@ -224,9 +229,9 @@ __global__ __launch_bounds__(64 * QF_WAVES) void quadform_kernel(const double* _
 #pragma unroll
   for (int r = 0; r < QF_ROWS; ++r) {
     acc[r] = wave_sum(acc[r]);
-    if (row0 + r < N) {
+    if (row0 + r < NR) {
       if (lane == 0 && y) y[row0 + r] = acc[r];
-      part += q[row0 + r] * acc[r];
+      part += q[row_begin + row0 + r] * acc[r];
     }
   }
   if (lane == 0) wpart[wave] = part;
@@ -252,16 +257,19 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
   if (threadIdx.x == 0) *out = red[0];
 }
 
-size_t quadform_partials(int n) {
-  const long long N = 1ll << n;
-  return (size_t)((N + QF_ROWS * QF_WAVES - 1) / (QF_ROWS * QF_WAVES));
+size_t quadform_partials(long long rows) {
+  return (size_t)((rows + QF_ROWS * QF_WAVES - 1) / (QF_ROWS * QF_WAVES));
 }
 
-hipError_t launch_quadform(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
-                           double* partials, double* /*ytmp*/, hipStream_t st) {
+// K holds rows [row_begin, row_end) of the Gram matrix; y (if given) receives those rows of K q,
+// ksd2 the partial sum over them of q_i y_i.
+hipError_t launch_quadform(int n, const double* K, long long row_begin, long long row_end, const double* q,
+                           double* y_or_null, double* ksd2, double* partials, hipStream_t st) {
   const long long N = 1ll << n;
-  const size_t nwg = quadform_partials(n);
-  quadform_kernel<<<(unsigned)nwg, 64 * QF_WAVES, 0, st>>>(K, q, y_or_null, partials, N);
+  const long long NR = row_end - row_begin;
+  const size_t nwg = quadform_partials(NR);
+  if (nwg == 0) return hipMemsetAsync(ksd2, 0, sizeof(double), st);
+  quadform_kernel<<<(unsigned)nwg, 64 * QF_WAVES, 0, st>>>(K, q, y_or_null, partials, N, row_begin, NR);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   sum_partials_kernel<<<1, 256, 0, st>>>(partials, (long long)nwg, ksd2);

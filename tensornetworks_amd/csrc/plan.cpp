@@ -107,6 +107,54 @@ void greedy_select(const std::vector<Op>& ops, const std::vector<int>& pool, int
   }
 }
 
+// Stage selection.  A stage runs its ops in five global phases -- 0: CNOTs (folded into the LDS read
+// address), 1: CZs, 2: at most one fused U per register wire, 3: CNOTs (folded into the write address),
+// 4: CZs -- so an op is accepted in the earliest phase its kind allows that is not before the phase of
+// the last op accepted on any of its wires (ops on disjoint wires commute).
+struct StageSel {
+  std::vector<int> pre_cx, pre_cz, us, post_cx, post_cz, targets;
+  size_t count() const { return pre_cx.size() + pre_cz.size() + us.size() + post_cx.size() + post_cz.size(); }
+};
+
+void stage_select(const std::vector<Op>& ops, const std::vector<int>& pool, int n, int cap, StageSel& S,
+                  std::vector<int>& rest) {
+  std::vector<char> blocked(n, 0), in_t(n, 0), has_u(n, 0);
+  std::vector<int> wphase(n, 0);
+  rest.clear();
+  for (int idx : pool) {
+    const Op& o = ops[idx];
+    bool blk = blocked[o.a] || (o.b >= 0 && blocked[o.b]);
+    int ph = -1;
+    if (!blk) {
+      const int mx = std::max(wphase[o.a], o.b >= 0 ? wphase[o.b] : 0);
+      if (o.kind == K_U1) ph = (mx <= 1 && !has_u[o.a]) ? 2 : -1;
+      else if (o.kind == K_CX) ph = mx <= 0 ? 0 : (mx <= 3 ? 3 : -1);
+      else ph = mx <= 1 ? 1 : (mx <= 4 ? 4 : -1);
+      if (ph < 0) blk = true;
+    }
+    const int t = op_target(o);
+    if (!blk && t >= 0 && !in_t[t]) {
+      if ((int)S.targets.size() < cap) { in_t[t] = 1; S.targets.push_back(t); }
+      else blk = true;
+    }
+    if (blk) {
+      blocked[o.a] = 1;
+      if (o.b >= 0) blocked[o.b] = 1;
+      rest.push_back(idx);
+      continue;
+    }
+    wphase[o.a] = std::max(wphase[o.a], ph);
+    if (o.b >= 0) wphase[o.b] = std::max(wphase[o.b], ph);
+    switch (ph) {
+      case 0: S.pre_cx.push_back(idx); break;
+      case 1: S.pre_cz.push_back(idx); break;
+      case 2: S.us.push_back(idx); has_u[o.a] = 1; break;
+      case 3: S.post_cx.push_back(idx); break;
+      default: S.post_cz.push_back(idx); break;
+    }
+  }
+}
+
 // Order LDS bit positions so that consecutive lanes are bank-conflict free under the
 // XOR-fold swizzle (phys low nibble = xor of all nibbles of the index): lane bits 0..2 go to
 // positions with residues {0,1,2} mod 4, lane bit 3 to residue 3, lane bit 4 to the residue of
@@ -328,15 +376,21 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       }
     }
     // ---- stages ----
-    std::vector<int> pool = P.ops, sel, rest, tg;
+    // Fixed form per stage (no runtime dispatch in the kernel):
+    //   load (CNOTs of phase 0 folded into the LDS read address) -> sign (CZs of phase 1)
+    //   -> at most one fused U per register wire (phase 2)
+    //   -> CNOTs of phase 3 folded into the LDS write address, sign of phase 4 evaluated on the
+    //      permuted index.  A CNOT whose target is a register wire only permutes amplitudes inside
+    //      the 2^r-element group a thread owns, so the in-place write-back needs no extra barrier.
+    std::vector<int> pool = P.ops, rest;
     uint32_t nstages = 0;
     while (!pool.empty()) {
-      greedy_select(ops, pool, n, r, sel, rest, tg);
-      if (sel.empty()) { msg = "stage planner made no progress"; return false; }
-      // register wires: targets, padded with local wires (highest LDS bits first: they cost nothing
-      // for coalescing and keep the low bits for the lanes)
+      StageSel sel;
+      stage_select(ops, pool, n, r, sel, rest);
+      if (sel.count() == 0) { msg = "stage planner made no progress"; return false; }
+      // register wires: targets, padded with local wires (highest LDS bits first)
       std::vector<char> isr(n, 0);
-      std::vector<int> regw = tg;
+      std::vector<int> regw = sel.targets;
       for (int w : regw) isr[w] = 1;
       for (int j = k - 1; j >= 0 && (int)regw.size() < r; --j)
         if (!isr[P.lds_wire[j]]) { isr[P.lds_wire[j]] = 1; regw.push_back(P.lds_wire[j]); }
@@ -349,50 +403,70 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       uint32_t tpos[4] = {0, 0, 0, 0};
       for (size_t j = 0; j < freepos.size() && j < 16; ++j) tpos[j / 4] |= (uint32_t)freepos[j] << (8 * (j % 4));
 
+      // symbolic composition of the CNOTs: register bit t = parity(areg & slot) ^ parity(bext & e)
+      struct Expr { uint32_t areg, bext; };
+      auto compose = [&](const std::vector<int>& seq, bool reverse, Expr (&ex)[4]) {
+        for (int t = 0; t < 4; ++t) ex[t] = Expr{1u << t, 0u};
+        for (size_t q = 0; q < seq.size(); ++q) {
+          const Op& o = ops[seq[reverse ? seq.size() - 1 - q : q]];
+          const int rt = regbit[o.b];
+          Expr ce = regbit[o.a] >= 0 ? ex[regbit[o.a]] : Expr{0u, 1u << extpos(o.a)};
+          ex[rt].areg ^= ce.areg; ex[rt].bext ^= ce.bext;
+        }
+      };
+      Expr pre[4], post[4];
+      compose(sel.pre_cx, true, pre);     // inverse map: where the amplitude of slot j is read from
+      compose(sel.post_cx, false, post);  // forward map: where the amplitude of slot j is written to
+      auto slot_offset = [&](const Expr (&ex)[4], int j) {
+        uint32_t off = 0;
+        for (int t = 0; t < r; ++t)
+          if (__builtin_popcount(ex[t].areg & (uint32_t)j) & 1) off |= 1u << ldspos[regw[t]];
+        return off;
+      };
+      auto emit_signq = [&](const std::vector<int>& czs, const Expr (&ex)[4]) {
+        uint32_t U[32]; std::memset(U, 0, sizeof(U));
+        uint32_t Sym[32]; std::memset(Sym, 0, sizeof(Sym));
+        for (int idx : czs) {
+          int ea = extpos(ops[idx].a), eb = extpos(ops[idx].b);
+          int lo2 = std::min(ea, eb), hi2 = std::max(ea, eb);
+          U[lo2] ^= 1u << hi2;               // CZ twice = identity, hence xor
+          Sym[lo2] ^= 1u << hi2; Sym[hi2] ^= 1u << lo2;
+        }
+        for (int a = 0; a < 32; ++a) W.push_back(U[a]);
+        uint32_t qbits = 0;
+        for (int j = 0; j < 16; ++j) {
+          uint32_t off = (j < (1 << r)) ? slot_offset(ex, j) : 0u, m = 0, qv = 0;
+          for (int a = 0; a < 32; ++a)
+            if (off >> a & 1) { m ^= Sym[a]; qv ^= (uint32_t)__builtin_popcount(off & U[a]) & 1u; }
+          W.push_back(m);
+          qbits |= qv << j;
+        }
+        W.push_back(qbits);
+      };
+
       const uint32_t sbase = (uint32_t)W.size();
       W.resize(sbase + STAGE_HDR_WORDS, 0);
       W[sbase + 1] = rho;
       for (int q = 0; q < 4; ++q) W[sbase + 2 + q] = tpos[q];
-      uint32_t nops = 0;
-      for (size_t s = 0; s < sel.size();) {
-        const Op& o = ops[sel[s]];
-        if (o.kind == K_U1) {
-          W.push_back(OP_U1 | ((uint32_t)regbit[o.a] << 4) | ((uint32_t)o.idx << 16));
-          ++nops; ++s;
-        } else if (o.kind == K_CX) {
-          if (regbit[o.a] >= 0) W.push_back(OP_CX_RR | ((uint32_t)regbit[o.a] << 4) | ((uint32_t)regbit[o.b] << 10));
-          else W.push_back(OP_CX_AR | ((uint32_t)extpos(o.a) << 4) | ((uint32_t)regbit[o.b] << 10));
-          ++nops; ++s;
-        } else {  // a run of CZ gates -> one sign quadratic form over the extended index
-          uint32_t U[32]; std::memset(U, 0, sizeof(U));
-          uint32_t Sym[32]; std::memset(Sym, 0, sizeof(Sym));
-          while (s < sel.size() && ops[sel[s]].kind == K_CZ) {
-            int ea = extpos(ops[sel[s]].a), eb = extpos(ops[sel[s]].b);
-            int lo2 = std::min(ea, eb), hi2 = std::max(ea, eb);
-            U[lo2] ^= 1u << hi2;               // CZ twice = identity, hence xor
-            Sym[lo2] ^= 1u << hi2; Sym[hi2] ^= 1u << lo2;
-            ++s;
-          }
-          W.push_back(OP_SIGNQ);
-          for (int a = 0; a < 32; ++a) W.push_back(U[a]);
-          uint32_t qbits = 0;
-          for (int j = 0; j < 16; ++j) {
-            uint32_t off = 0, m = 0;
-            for (int b = 0; b < r; ++b) if (j >> b & 1) { off |= 1u << ldspos[regw[b]]; m ^= Sym[ldspos[regw[b]]]; }
-            uint32_t qv = 0;
-            for (int a = 0; a < 32; ++a) if (off >> a & 1) qv ^= (uint32_t)__builtin_popcount(off & U[a]) & 1u;
-            if (j >= (1 << r)) { m = 0; qv = 0; }
-            W.push_back(m);
-            qbits |= qv << j;
-          }
-          W.push_back(qbits);
-          ++nops;
-        }
+      uint32_t fidx[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+      for (int idx : sel.us) fidx[regbit[ops[idx].a]] = (uint32_t)ops[idx].idx;
+      W[sbase + 6] = fidx[0] | (fidx[1] << 16);
+      W[sbase + 7] = fidx[2] | (fidx[3] << 16);
+      for (int t = 0; t < 4; ++t) { W[sbase + 8 + t] = t < r ? pre[t].bext : 0u; W[sbase + 12 + t] = t < r ? post[t].bext : 0u; }
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t lo_ = (j < (1 << r)) ? lds_swizzle(slot_offset(pre, j)) : 0u;
+        const uint32_t so_ = (j < (1 << r)) ? lds_swizzle(slot_offset(post, j)) : 0u;
+        W[sbase + 16 + j / 2] |= lo_ << (16 * (j & 1));
+        W[sbase + 24 + j / 2] |= so_ << (16 * (j & 1));
       }
-      // word 0: r | nops << 8 | (words in this stage) << 16, so the kernel can step to the next one
+      uint32_t flags = 0;
+      Expr ident[4];
+      for (int t = 0; t < 4; ++t) ident[t] = Expr{1u << t, 0u};
+      if (!sel.pre_cz.empty()) { flags |= STAGE_SIGN_PRE; emit_signq(sel.pre_cz, ident); }
+      if (!sel.post_cz.empty()) { flags |= STAGE_SIGN_POST; emit_signq(sel.post_cz, post); }
       const uint32_t nwords = (uint32_t)W.size() - sbase;
-      if (nwords >= (1u << 16) || nops >= 256) { msg = "stage too large"; return false; }
-      W[sbase] = (uint32_t)r | (nops << 8) | (nwords << 16);
+      if (nwords >= (1u << 16)) { msg = "stage too large"; return false; }
+      W[sbase] = (uint32_t)r | (flags << 8) | (nwords << 16);
       ++nstages;
       pool = rest;
     }

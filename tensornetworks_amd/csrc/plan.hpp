@@ -61,19 +61,32 @@ enum PassWords : int {
 constexpr uint32_t PASS_INIT = 1u;   // tile starts as |0...0> (no HBM read)
 constexpr uint32_t PASS_FINAL = 2u;  // epilogue writes |psi|^2 in canonical order
 constexpr uint32_t PASS_FINAL_STATE = 4u;  // epilogue writes the state itself in canonical order
-// stage: [0] r | nops << 8 | nwords << 16   [1] rho (4 bytes: LDS bit of register bit i)
-//        [2..5] tpos (16 bytes: LDS bit receiving thread bit j)   [6..] ops
-constexpr int STAGE_HDR_WORDS = 6;
-// op word: kind (bits 0-3) | a (bits 4-9) | b (bits 10-15) | idx (bits 16-31)
-enum OpKind : uint32_t {
-  OP_U1 = 1,     // a = register bit, idx = fused gate index
-  OP_CX_RR = 2,  // a = control register bit, b = target register bit
-  OP_CX_AR = 3,  // a = control position in the extended index, b = target register bit
-  OP_SIGNQ = 4   // followed by SIGNQ_WORDS words
-};
-// SIGNQ payload: [0..31] U rows (upper-triangular adjacency over extended index bits),
-//                [32..47] m_j (bilinear masks of the 16 register offsets), [48] q bits of the offsets
+// stage (fixed form, see plan.cpp): STAGE_HDR_WORDS words, then optional sign payloads
+//   [0]      r | flags << 8 | nwords << 16
+//   [1]      rho: 4 bytes, LDS bit position of register bit t
+//   [2..5]   tpos: 16 bytes, LDS bit position receiving thread-id bit j
+//   [6..7]   fused gate index of register bit t (16 bits each, 0xffff = no gate)
+//   [8..11]  Bpre[t]:  parity(e & Bpre[t]) flips register bit t of the LDS READ index
+//   [12..15] Bpost[t]: same for the LDS WRITE index        (e = extended index: LDS bits, then workgroup bits)
+//   [16..23] load_off[16]:  16 bits each, swizzled LDS offset register slot j is read from
+//   [24..31] store_off[16]: 16 bits each, swizzled LDS offset register slot j is written to
+//   then SIGNQ_WORDS words if STAGE_SIGN_PRE, then SIGNQ_WORDS words if STAGE_SIGN_POST
+constexpr int STAGE_HDR_WORDS = 32;
+constexpr uint32_t STAGE_SIGN_PRE = 1u;
+constexpr uint32_t STAGE_SIGN_POST = 2u;
+// sign payload (product of CZ gates = (-1)^{q(x)}, q a quadratic form over the extended index bits):
+//   [0..31] U rows (upper-triangular adjacency), [32..47] m_j (bilinear masks of the 16 slot
+//   offsets), [48] q bits of the slot offsets
 constexpr int SIGNQ_WORDS = 49;
+
+// LDS index swizzle shared by planner and kernel: xor-fold the upper nibbles into the low nibble.
+// Linear over GF(2), its own inverse, keeps bits >= 4.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define BORNVI_HD __host__ __device__
+#else
+#define BORNVI_HD
+#endif
+BORNVI_HD inline uint32_t lds_swizzle(uint32_t l) { return l ^ (((l >> 4) ^ (l >> 8) ^ (l >> 12)) & 15u); }
 
 struct PlanOptions {
   int kmax = 13;     // tile bits (2^13 complex128 = 128 KiB of LDS)

@@ -32,6 +32,26 @@ from .utils import calculate_tvd, generate_all_binary_outcomes
 DENSE_GRAM_MAX_N = 16     # 8 * 4^16 bytes = 32 GiB of the 288 GB HBM; beyond that the matrix-free form
 
 
+class _EventSpan:
+    """`with` block that records a (start, end) torch.cuda.Event pair on the current stream -- the
+    stream every bornvi kernel of the block is launched on -- when timers are enabled."""
+
+    def __init__(self, timers, name):
+        self.timers, self.name = timers, name
+
+    def __enter__(self):
+        if self.timers is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timers is not None:
+            self.ev[1].record()
+            self.timers.setdefault(self.name, []).append(self.ev)
+        return False
+
+
 class KSDVariationalInference:
     def __init__(self,
                  bayesian_network,
@@ -81,8 +101,10 @@ class KSDVariationalInference:
 
         self._score_function_cache = {}
         self._S = None          # scores [2^n, n] on the GPU
-        self._K = None          # dense Gram (dense mode)
+        self._K = None          # dense Gram (dense mode): all rows, or this rank's row block when sharded
+        self._K_rows = None     # (row_begin, row_end) held in self._K
         self._stein_key = None
+        self.timers = None      # optional {name: [(start_event, end_event), ...]} filled by ksd_and_grad
 
     # ---- reference attribute kept lazily (2^n Python tuples) -------------------------------------------
     @property
@@ -122,11 +144,43 @@ class KSDVariationalInference:
         return self.num_latent_vars <= DENSE_GRAM_MAX_N
 
     def _prepare_stein(self, x_dict, announce=True):
+        """Scores and (dense mode) the Gram matrix, once per observation.  With W > 1 ranks each rank
+        builds and keeps only its block of N/W rows of K_p (row shard of the quadratic form)."""
         dev = backend.compute_device(self.pytorch_device)
+        n = self.num_latent_vars
         self._S = score_matrix(self.bn, x_dict, self.latent_vars_names, device=dev)
-        self._K = stein_gram_matrix(self._S, self.num_latent_vars, self.base_kernel_length_scale) \
-            if self._use_dense() else None
+        self._K = None
+        self._K_rows = None
+        if self._use_dense():
+            rank, ws = shard.world(self.process_group)
+            self._K_rows = shard.shard_range(1 << n, rank, ws)
+            self._K = backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
         self._stein_key = self._key(x_dict)
+
+    def _timed(self, name):
+        return _EventSpan(self.timers, name)
+
+    def _stein_contract(self, q):
+        """(ksd2 [1], y = K_p q [2^n]) for the current q, on the GPU."""
+        n = self.num_latent_vars
+        if self._K is None:
+            return backend.stein_matvec_kron(self._S, q, n, self.base_kernel_length_scale)
+        rank, ws = shard.world(self.process_group)
+        r0, r1 = self._K_rows
+        if ws == 1:
+            ksd2, Y = backend.stein_quadform(self._K, q, n, want_y=True)
+            return ksd2, Y[0]
+        # row shard: every rank contributes its rows of K q plus its partial of q.y in one all-gather
+        chunk = -(-(1 << n) // ws)
+        msg = torch.zeros(chunk + 1, dtype=torch.float64, device=q.device)
+        part = backend.stein_quadform_rows(self._K, r0, r1, q, n)
+        msg[: r1 - r0] = part[:-1]
+        msg[chunk] = part[-1]
+        full = torch.empty((ws, chunk + 1), dtype=torch.float64, device=q.device)
+        torch.distributed.all_gather_into_tensor(full.view(-1), msg, group=self.process_group)
+        y = full[:, :chunk].reshape(-1)[: 1 << n].contiguous()
+        ksd2 = full[:, chunk].sum().reshape(1)      # fixed rank order: identical on every rank
+        return ksd2, y
 
     # ---- one KSD-gradient step on the device -------------------------------------------------------------
     def ksd_and_grad(self, theta64=None):
@@ -140,16 +194,47 @@ class KSDVariationalInference:
         P = theta64.numel()
         rank, ws = shard.world(self.process_group)
         lo, hi = shard.shard_range(P, rank, ws)
-        probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True)
+        with self._timed("circuits"):
+            probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True)
         q = probs[0]
-        if self._K is not None:
-            ksd2, Y = backend.stein_quadform(self._K, q, n, want_y=True)
-            y = Y[0]
-        else:
-            ksd2, y = backend.stein_matvec_kron(self._S, q, n, self.base_kernel_length_scale)
-        loss, grad_local, _ = backend.ksd_grad_finish(n, probs[1:], hi - lo, y, ksd2)
-        grad = shard.all_gather_grad(grad_local, P, self.process_group)
+        with self._timed("stein"):
+            ksd2, y = self._stein_contract(q)
+        with self._timed("finish"):
+            loss, grad_local, _ = backend.ksd_grad_finish(n, probs[1:], hi - lo, y, ksd2)
+            grad = shard.all_gather_grad(grad_local, P, self.process_group)
         return loss, grad, q
+
+    def make_optimizer(self, lr_born_machine, num_epochs, use_lr_scheduler=True, optimizer_type="adam",
+                       adam_betas=(0.9, 0.999)):
+        """Optimiser and scheduler exactly as the reference builds them (ksd_vi_quantum.py:92-103)."""
+        params = list(self.born_machine.parameters())
+        if optimizer_type == "adam":
+            optimizer_born = optim.Adam(params, lr=lr_born_machine, betas=adam_betas)
+        elif optimizer_type == "sgd":
+            optimizer_born = optim.SGD(params, lr=lr_born_machine, momentum=0.9)
+        else:
+            optimizer_born = optim.Adam(params, lr=lr_born_machine)
+        scheduler = None
+        if use_lr_scheduler:
+            scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer_born, T_max=num_epochs,
+                                                             eta_min=lr_born_machine / 10)
+        return params, optimizer_born, scheduler
+
+    def training_step(self, params, optimizer_born, scheduler, gradient_clip_norm):
+        """One epoch body (reference :111-161) without the logging: device step, NaN/Inf guard, clip,
+        optimiser and scheduler step.  Returns (loss_value, grad_norm or None if skipped, q)."""
+        optimizer_born.zero_grad()
+        loss_t, grad64, q = self.ksd_and_grad()
+        loss_value = float(loss_t.item())        # the epoch's one host sync (reference: loss.item(), :163)
+        if np.isnan(loss_value) or np.isinf(loss_value):
+            return loss_value, None, q
+        theta = self.born_machine.theta
+        theta.grad = grad64.to(device=theta.device, dtype=theta.dtype)
+        grad_norm = nn_utils.clip_grad_norm_(params, gradient_clip_norm)
+        optimizer_born.step()
+        if scheduler is not None:
+            scheduler.step()
+        return loss_value, grad_norm, q
 
     def train(self, x_observation_dict, num_epochs, lr_born_machine,
               verbose=True, true_posterior_for_tvd=None,
@@ -166,32 +251,19 @@ class KSDVariationalInference:
 
         self._precompute_all_s_p(x_observation_dict)
 
-        params = list(self.born_machine.parameters())
-        if optimizer_type == "adam":
-            optimizer_born = optim.Adam(params, lr=lr_born_machine, betas=adam_betas)
-        elif optimizer_type == "sgd":
-            optimizer_born = optim.SGD(params, lr=lr_born_machine, momentum=0.9)
-        else:
-            optimizer_born = optim.Adam(params, lr=lr_born_machine)
-
-        scheduler = None
-        if use_lr_scheduler:
-            scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer_born, T_max=num_epochs,
-                                                             eta_min=lr_born_machine / 10)
+        params, optimizer_born, scheduler = self.make_optimizer(lr_born_machine, num_epochs, use_lr_scheduler,
+                                                                optimizer_type, adam_betas)
 
         history = {'loss_ksd': [], 'tvd': [], 'grad_norm': []}
         best_tvd = float('inf')
         best_params = None
         grad_norm = None
-        theta = self.born_machine.theta
         log_every = (num_epochs // 10 if num_epochs >= 10 else 1)
 
         for epoch in range(num_epochs):
-            optimizer_born.zero_grad()
-
             if self.born_machine.conditioning_dim > 0 and qbm_x_condition_input is not None:
                 print("Warning: Conditioning with x_condition not fully implemented in PQC ansatz yet.")
-            loss_t, grad64, q = self.ksd_and_grad()
+            loss_value, step_norm, q = self.training_step(params, optimizer_born, scheduler, gradient_clip_norm)
 
             if verbose and epoch % log_every == 0:
                 print(f"  Epoch {epoch+1} Q Probs (first 4): {q[:4].detach().cpu().numpy()}")
@@ -199,17 +271,12 @@ class KSDVariationalInference:
             if q.shape[0] != self.num_possible_latent_states:
                 raise ValueError(f"Probabilities from Born machine have unexpected shape")
 
-            loss_value = float(loss_t.item())        # the epoch's one host sync (reference: loss.item(), :163)
-            if np.isnan(loss_value) or np.isinf(loss_value):
+            if step_norm is None:
                 print(f"Warning: NaN or Inf KSD loss: {loss_value}. Skipping update.")
             else:
-                theta.grad = grad64.to(device=theta.device, dtype=theta.dtype)
-                grad_norm = nn_utils.clip_grad_norm_(params, gradient_clip_norm)
+                grad_norm = step_norm
                 if verbose and epoch % log_every == 0:
                     print(f"  Epoch {epoch+1} Grad Norm (after clipping): {grad_norm:.4f}")
-                optimizer_born.step()
-                if scheduler is not None:
-                    scheduler.step()
 
             history['loss_ksd'].append(loss_value)
             history['grad_norm'].append(grad_norm if grad_norm is not None else 0.0)

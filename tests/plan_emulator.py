@@ -3,7 +3,8 @@
 Interprets the uint32 plan produced by the C++ planner (bornvi_plan_describe) exactly as
 circuit_pass_kernel does -- same tile/bit-permutation arithmetic, same stage/thread/register
 decomposition, same micro-ops -- but on NumPy arrays, so that the planner can be validated
-against the oracle without a GPU.  (The LDS swizzle is an address-only detail and is skipped.)
+against the oracle without a GPU.  The LDS swizzle is emulated too: the tile array is indexed by LOGICAL index, the swizzled
+addresses the kernel forms are mapped back through the (involutive) swizzle.
 """
 import numpy as np
 
@@ -14,8 +15,8 @@ FUSED_WORDS = 10
 PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
 PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_LDS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_STAGES = 8, 40, 72, 104, 136, 168, 200, 232
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
-STAGE_HDR_WORDS = 6
-OP_U1, OP_CX_RR, OP_CX_AR, OP_SIGNQ = 1, 2, 3, 4
+STAGE_HDR_WORDS = 32
+STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
 SIGNQ_WORDS = 49
 KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
 
@@ -32,6 +33,24 @@ def fused_matrices(W, theta):
             U = oc.matrix_1q(KIND_NAMES[kind], t) @ U
         mats.append(U)
     return mats
+
+
+def swz(l):
+    """lds_swizzle of plan.hpp (linear over GF(2), an involution)."""
+    return l ^ (((l >> 4) ^ (l >> 8) ^ (l >> 12)) & 15)
+
+
+swz_inv = swz
+
+
+def apply_sign(Q, e, n, amp, nreg):
+    acc = np.zeros(e.shape, dtype=np.uint64)
+    for q in range(n):
+        acc ^= ((e >> q) & 1).astype(np.uint64) & popc(e & int(Q[q]))
+    qbits = int(Q[48])
+    for j in range(nreg):
+        sgn = (((qbits >> j) & 1) ^ (acc & np.uint64(1)) ^ (popc(e & int(Q[32 + j])) & np.uint64(1))).astype(bool)
+        amp[j] = np.where(sgn, -amp[j], amp[j])
 
 
 def popc(x):
@@ -77,7 +96,7 @@ def run_plan(W, mats, state_in=None):
                 tile = buf[phys]
             S = P[PW_STAGES:]
             for _ in range(nst):
-                hdr = int(S[0]); r = hdr & 0xFF; nops = (hdr >> 8) & 0xFF; nwords = hdr >> 16
+                hdr = int(S[0]); r = hdr & 0xFF; sflags = (hdr >> 8) & 0xFF; nwords = hdr >> 16
                 rho = int(S[1])
                 nthr = 1 << (k - r)
                 assert nthr <= T
@@ -88,55 +107,51 @@ def run_plan(W, mats, state_in=None):
                     base |= ((t >> j) & 1) << pos
                 rpos = [(rho >> (8 * i)) & 0xFF for i in range(r)]
                 nreg = 1 << r
-                offs = [sum(((j >> i) & 1) << rpos[i] for i in range(r)) for j in range(nreg)]
-                # every LDS element is owned by exactly one (thread, register) pair
-                own = np.concatenate([base ^ o for o in offs])
-                assert np.array_equal(np.sort(own), np.arange(ksize))
-                amp = [tile[base ^ o].copy() for o in offs] + [np.zeros(nthr, np.complex128)] * (16 - nreg)
+                fi = [int(S[6]) & 0xFFFF, int(S[6]) >> 16, int(S[7]) & 0xFFFF, int(S[7]) >> 16]
                 e = base | (g << k)
-                op = STAGE_HDR_WORDS
-                for _o in range(nops):
-                    w = int(S[op]); op += 1
-                    kind, a, b, idx = w & 15, (w >> 4) & 63, (w >> 10) & 63, w >> 16
-                    if kind == OP_U1:
-                        U = mats[idx]
-                        assert a < r
-                        for j in range(nreg):
-                            if j & (1 << a):
-                                continue
-                            j1 = j | (1 << a)
-                            x0, x1 = amp[j], amp[j1]
-                            amp[j], amp[j1] = U[0, 0] * x0 + U[0, 1] * x1, U[1, 0] * x0 + U[1, 1] * x1
-                    elif kind == OP_CX_RR:
-                        assert a < r and b < r and a != b
-                        for j in range(nreg):
-                            if (j & (1 << a)) and not (j & (1 << b)):
-                                j1 = j | (1 << b)
-                                amp[j], amp[j1] = amp[j1], amp[j]
-                    elif kind == OP_CX_AR:
-                        assert b < r and a < n and a not in rpos
-                        c = ((e >> a) & 1).astype(bool)
-                        for j in range(nreg):
-                            if not (j & (1 << b)):
-                                j1 = j | (1 << b)
-                                a0, a1 = amp[j], amp[j1]
-                                amp[j], amp[j1] = np.where(c, a1, a0), np.where(c, a0, a1)
-                    elif kind == OP_SIGNQ:
-                        Q = S[op: op + SIGNQ_WORDS]
-                        acc = np.zeros(nthr, dtype=np.uint64)
-                        for q in range(n):
-                            row = int(Q[q])
-                            acc ^= ((e >> q) & 1).astype(np.uint64) & popc(e & row)
-                        qbits = int(Q[48])
-                        for j in range(nreg):
-                            sgn = (((qbits >> j) & 1) ^ (acc & np.uint64(1)) ^ (popc(e & int(Q[32 + j])) & np.uint64(1))).astype(bool)
-                            amp[j] = np.where(sgn, -amp[j], amp[j])
-                        op += SIGNQ_WORDS
-                    else:
-                        raise AssertionError(f"bad op kind {kind}")
-                assert op == nwords, (op, nwords)
+                pb = swz(base)
+                lflip = np.zeros(nthr, dtype=np.int64); sflip = np.zeros(nthr, dtype=np.int64); e2 = e.copy()
+                for i in range(r):
+                    sri = swz(1 << rpos[i])
+                    bpre, bpost = int(S[8 + i]), int(S[12 + i])
+                    lflip ^= (popc(e & bpre) & np.uint64(1)).astype(np.int64) * sri
+                    bit = (popc(e & bpost) & np.uint64(1)).astype(np.int64)
+                    sflip ^= bit * sri
+                    e2 |= bit << rpos[i]
+                for i in range(r, 4):
+                    assert int(S[8 + i]) == 0 and int(S[12 + i]) == 0
+                loff = [(int(S[16 + (j >> 1)]) >> (16 * (j & 1))) & 0xFFFF for j in range(16)]
+                soff = [(int(S[24 + (j >> 1)]) >> (16 * (j & 1))) & 0xFFFF for j in range(16)]
+                rd = [swz_inv(pb ^ lflip ^ loff[j]) for j in range(nreg)]
+                wr = [swz_inv(pb ^ sflip ^ soff[j]) for j in range(nreg)]
+                # a thread reads and writes exactly its own 2^r-element group (no cross-thread hazard),
+                # and the groups partition the tile
+                own = np.sort(np.stack([base ^ sum(((j >> i) & 1) << rpos[i] for i in range(r)) for j in range(nreg)]), axis=0)
+                assert np.array_equal(np.sort(np.stack(rd), axis=0), own)
+                assert np.array_equal(np.sort(np.stack(wr), axis=0), own)
+                assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(ksize))
+                amp = [tile[rd[j]].copy() for j in range(nreg)] + [np.zeros(nthr, np.complex128)] * (16 - nreg)
+                q_off = STAGE_HDR_WORDS
+                if sflags & STAGE_SIGN_PRE:
+                    apply_sign(S[q_off: q_off + SIGNQ_WORDS], e, n, amp, nreg)
+                    q_off += SIGNQ_WORDS
+                for a in range(4):
+                    if fi[a] == 0xFFFF:
+                        continue
+                    assert a < r
+                    U = mats[fi[a]]
+                    for j in range(nreg):
+                        if j & (1 << a):
+                            continue
+                        j1 = j | (1 << a)
+                        x0, x1 = amp[j], amp[j1]
+                        amp[j], amp[j1] = U[0, 0] * x0 + U[0, 1] * x1, U[1, 0] * x0 + U[1, 1] * x1
+                if sflags & STAGE_SIGN_POST:
+                    apply_sign(S[q_off: q_off + SIGNQ_WORDS], e2, n, amp, nreg)
+                    q_off += SIGNQ_WORDS
+                assert q_off == nwords, (q_off, nwords)
                 for j in range(nreg):
-                    tile[base ^ offs[j]] = amp[j]
+                    tile[wr[j]] = amp[j]
                 S = S[nwords:]
             # store
             v = np.arange(ksize, dtype=np.int64)
