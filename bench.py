@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gate-bench", action="store_true")
     ap.add_argument("--tile-bits", type=int, default=0)
+    ap.add_argument("--debug-flags", type=int, default=0, help="timing-only kernel ablations (results invalid)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +139,8 @@ def main():
     n, layers, ansatz, gram_mode = WORKLOADS[args.workload]
     if args.tile_bits:
         backend.set_option(dev, "tile_bits", args.tile_bits)
+    if args.debug_flags:
+        backend.set_option(dev, "debug_flags", args.debug_flags)
     bn, lat, obs, x = synthetic_network(n, seed=0)
     torch.manual_seed(0)
     vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,

@@ -34,6 +34,7 @@ struct bornvi_ctx {
   PlanOptions opt;
   std::map<std::tuple<int, int, int>, std::unique_ptr<DevPlan>> plans;  // (ansatz | -1 = kron, n, layers)
   size_t max_lds_prepared = 0;
+  int debug_flags = 0;  // timing-only ablations of circuit_pass_kernel (results are WRONG when non-zero)
 };
 
 namespace {
@@ -87,7 +88,7 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
   for (int i = 0; i < p.n_passes; ++i) {
     const bool last = (i == p.n_passes - 1);
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
-    HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, bc, in, out, final_probs, gates, gate_stride, st));
+    HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, bc, in, out, final_probs, gates, gate_stride, h->debug_flags, st));
     in = out;
   }
   return BORNVI_OK;
@@ -166,6 +167,7 @@ const char* bornvi_last_error(bornvi_handle h) { return h ? h->err.c_str() : g_c
 
 int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   if (!h || !name) return BORNVI_ERR_INVALID;
+  if (!std::strcmp(name, "debug_flags")) { h->debug_flags = (int)value; return BORNVI_OK; }
   PlanOptions o = h->opt;
   if (!std::strcmp(name, "tile_bits")) o.kmax = (int)value;
   else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;

@@ -89,7 +89,10 @@ __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const doub
 // arrays would go to scratch)
 // ------------------------------------------------------------------------------------------------
 template <int I>
-__device__ __forceinline__ void op_u1(double (&ar)[16], double (&ai)[16], const double (&U)[8]) {
+__device__ __forceinline__ void op_u1(double (&ar)[16], double (&ai)[16], const double2* __restrict__ Um) {
+  // the matrix is read from LDS at a wave-uniform address (broadcast), right before its use
+  const double2 u00 = Um[0], u01 = Um[1], u10 = Um[2], u11 = Um[3];
+  const double U[8] = {u00.x, u00.y, u01.x, u01.y, u10.x, u10.y, u11.x, u11.y};
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     if (j & (1 << I)) continue;
@@ -119,46 +122,95 @@ __device__ __forceinline__ void apply_sign(const uint32_t* __restrict__ Q, uint3
   }
 }
 
-__device__ __forceinline__ uint32_t deposit_bits(uint32_t v, int from, int to, const uint32_t* __restrict__ pos) {
+// Byte `idx` (0..15, may be a run-time but wave-uniform value) of a 16-byte table held in four
+// registers: two 64-bit shifts instead of a dependent memory load.
+__device__ __forceinline__ uint32_t byte16(const uint32_t (&w)[4], uint32_t idx) {
+  const unsigned long long lo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+  const unsigned long long hi = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+  const unsigned long long v = (idx & 8u) ? hi : lo;
+  return (uint32_t)(v >> (8u * (idx & 7u))) & 0xffu;
+}
+
+// sum over bits j in [from, to) of bit_j(v) << table[j]; fully unrolled so the table stays in registers
+__device__ __forceinline__ uint32_t deposit16(uint32_t v, int from, int to, const uint32_t (&table)[4]) {
   uint32_t o = 0;
-  for (int j = from; j < to; ++j) o |= ((v >> j) & 1u) << pos[j];
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j >= from && j < to) o |= ((v >> j) & 1u) << ((table[j >> 2] >> (8 * (j & 3))) & 0xffu);
   return o;
 }
 
+constexpr int MAX_TILE_ITERS = 16;  // tile elements per thread in the HBM <-> LDS phases (2^13 / 512)
+
 // One pass of the circuit program over one 2^k-amplitude tile per workgroup.
 // grid = (2^(n-k) tiles, circuits); block = plan threads; dynamic LDS = 2^k * 16 bytes.
+// FULL = every thread moves exactly MAX_TILE_ITERS tile elements (k >= 10: threads = 2^(k-4)), which lets
+// all loads of the tile stay in registers; the generic instantiation handles small tiles.
+template <bool FULL>
 __global__ __launch_bounds__(512) void circuit_pass_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const double2* __restrict__ in,
     double2* __restrict__ out, double* __restrict__ probs, const double* __restrict__ gates,
-    long long gate_stride, long long state_stride) {
+    long long gate_stride, long long state_stride, int dbg) {
   extern __shared__ double2 tile[];
   const uint32_t* __restrict__ P = plan + pass_off;
-  const uint32_t flags = P[PW_FLAGS];
-  const int k = (int)P[PW_K], n = (int)P[PW_N];
-  const int nstages = (int)P[PW_NSTAGES];
-  const int lo_in = (int)P[PW_LO_IN], lo_out = (int)P[PW_LO_OUT];
+  uint32_t H[PW_HEADER_WORDS];   // whole pass header with two wide scalar loads
+#pragma unroll
+  for (int i = 0; i < PW_HEADER_WORDS; ++i) H[i] = P[i];
+  const uint32_t flags = H[PW_FLAGS];
+  const int k = (int)H[PW_K], n = (int)H[PW_N];
+  const int nstages = (int)H[PW_NSTAGES];
+  const int lo_in = (int)H[PW_LO_IN], lo_out = (int)H[PW_LO_OUT];
+  const uint32_t in_phys[4] = {H[PW_IN_PHYS], H[PW_IN_PHYS + 1], H[PW_IN_PHYS + 2], H[PW_IN_PHYS + 3]};
+  const uint32_t in_gphys[4] = {H[PW_IN_GPHYS], H[PW_IN_GPHYS + 1], H[PW_IN_GPHYS + 2], H[PW_IN_GPHYS + 3]};
+  const uint32_t out_lds[4] = {H[PW_OUT_LDS], H[PW_OUT_LDS + 1], H[PW_OUT_LDS + 2], H[PW_OUT_LDS + 3]};
+  const uint32_t out_phys[4] = {H[PW_OUT_PHYS], H[PW_OUT_PHYS + 1], H[PW_OUT_PHYS + 2], H[PW_OUT_PHYS + 3]};
+  const uint32_t out_gphys[4] = {H[PW_OUT_GPHYS], H[PW_OUT_GPHYS + 1], H[PW_OUT_GPHYS + 2], H[PW_OUT_GPHYS + 3]};
   const uint32_t t = threadIdx.x, T = blockDim.x;
   const int tau = 31 - __clz((int)T);
   const int kt = tau < k ? tau : k;  // index bits supplied by the thread id
   const uint32_t g = blockIdx.x;
   const long long b = blockIdx.y;
   const uint32_t ksize = 1u << k;
-  const int niter = 1 << (k - kt);
+  const int niter = 1 << (k - kt);    // <= MAX_TILE_ITERS (checked by the planner: threads >= 2^(k-4))
+  double2* __restrict__ mats = tile + ksize;   // [nstages][4 register bits][4 double2] fused matrices of circuit b
+
+  // ---- this circuit's fused matrices for every stage of the pass -> LDS (one 16-byte piece per thread;
+  // they were written by build_gates_kernel on other CUs, i.e. they come from far memory: fetch them once,
+  // under the tile loads, instead of stalling every stage on them)
+  for (uint32_t piece = t; piece < (uint32_t)nstages * 16u; piece += T) {
+    const uint32_t sm = piece >> 2;                               // (stage, register bit)
+    const uint32_t w = P[PW_MATS + (sm >> 1)];
+    const uint32_t f = (sm & 1u) ? (w >> 16) : (w & 0xffffu);
+    if (f != 0xffffu)
+      mats[piece] = reinterpret_cast<const double2*>(gates + b * gate_stride + (size_t)f * 8)[piece & 3u];
+  }
 
   // ---- tile in: HBM (pass-specific bit order) -> LDS, or |0...0> ---------------------------------
   if (flags & PASS_INIT) {
     for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
-  } else if (t < ksize) {
-    uint32_t gin = 0;
-    for (int m = 0; m < n - k; ++m) gin |= ((g >> m) & 1u) << P[PW_IN_GPHYS + m];
+  } else if (t < ksize && !(dbg & 4)) {
+    const uint32_t gin = deposit16(g, 0, n - k, in_gphys);
     const double2* __restrict__ src = in + b * state_stride + gin;
-    const uint32_t thr = (t & ((1u << lo_in) - 1u)) | deposit_bits(t, lo_in, kt, P + PW_IN_PHYS);
-#pragma unroll 4
-    for (int i = 0; i < niter; ++i) {
-      uint32_t itp = 0;
-      for (int j = kt; j < k; ++j) itp |= (((uint32_t)i >> (j - kt)) & 1u) << P[PW_IN_PHYS + j];
-      const uint32_t u = t | ((uint32_t)i << kt);
-      tile[lds_swizzle(u)] = src[thr | itp];
+    const uint32_t thr = (t & ((1u << lo_in) - 1u)) | deposit16(t, lo_in, kt, in_phys);
+    uint32_t ipos[4];                 // phys-in position of the index bits supplied by the iteration count
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ipos[m] = (kt + m < k) ? byte16(in_phys, (uint32_t)(kt + m)) : 0u;
+    if (FULL) {
+      double2 v[MAX_TILE_ITERS];      // every load of the tile is in flight before the first LDS write
+#pragma unroll
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+        const uint32_t itp = ((i & 1) ? 1u << ipos[0] : 0u) | ((i & 2) ? 1u << ipos[1] : 0u) |
+                             ((i & 4) ? 1u << ipos[2] : 0u) | ((i & 8) ? 1u << ipos[3] : 0u);
+        v[i] = src[thr | itp];
+      }
+#pragma unroll
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) tile[lds_swizzle(t | ((uint32_t)i << kt))] = v[i];
+    } else {
+      for (int i = 0; i < niter; ++i) {
+        const uint32_t itp = ((i & 1) ? 1u << ipos[0] : 0u) | ((i & 2) ? 1u << ipos[1] : 0u) |
+                             ((i & 4) ? 1u << ipos[2] : 0u) | ((i & 8) ? 1u << ipos[3] : 0u);
+        tile[lds_swizzle(t | ((uint32_t)i << kt))] = src[thr | itp];
+      }
     }
   }
   __syncthreads();
@@ -169,23 +221,19 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
   // the permuted index, write with the phase-3 CNOT permutation folded into the address.
   const uint32_t* __restrict__ S = P + PW_STAGES;
   for (int s = 0; s < nstages; ++s) {
-    const uint32_t hdr = S[0];
+    uint32_t G[STAGE_HDR_WORDS];     // stage header with two wide scalar loads
+#pragma unroll
+    for (int i = 0; i < STAGE_HDR_WORDS; ++i) G[i] = S[i];
+    const uint32_t hdr = G[0];
     const int r = (int)(hdr & 0xffu);
     const uint32_t sflags = (hdr >> 8) & 0xffu;
     const uint32_t nwords = hdr >> 16;
     if (t < (1u << (k - r))) {
-      const uint32_t rho = S[1];
-      const uint32_t f01 = S[6], f23 = S[7];
-      const uint32_t fi[4] = {f01 & 0xffffu, f01 >> 16, f23 & 0xffffu, f23 >> 16};
-      double U[4][8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const double* __restrict__ Ug = gates + b * gate_stride + (size_t)(fi[i] == 0xffffu ? 0u : fi[i]) * 8;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) U[i][q] = Ug[q];
-      }
-      uint32_t base = 0;
-      for (int j = 0; j < k - r; ++j) base |= ((t >> j) & 1u) << ((S[2 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
+      const uint32_t rho = G[1];
+      const uint32_t fi[4] = {G[6] & 0xffffu, G[6] >> 16, G[7] & 0xffffu, G[7] >> 16};
+      const double2* __restrict__ Us = mats + s * 16;
+      const uint32_t tpos[4] = {G[2], G[3], G[4], G[5]};
+      const uint32_t base = deposit16(t, 0, k - r, tpos);
       const uint32_t pb = lds_swizzle(base);
       const uint32_t e = base | (g << k);  // extended index: LDS bits then workgroup bits
       uint32_t lflip = 0, sflip = 0, e2 = e;
@@ -193,7 +241,7 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
       for (int i = 0; i < 4; ++i) {
         const uint32_t rp = (rho >> (8 * i)) & 0xffu;
         const uint32_t sri = (i < r) ? lds_swizzle(1u << rp) : 0u;
-        const uint32_t bpre = S[8 + i], bpost = S[12 + i];
+        const uint32_t bpre = G[8 + i], bpost = G[12 + i];
         if (bpre) lflip ^= (__popc(e & bpre) & 1) ? sri : 0u;
         if (bpost) {
           const uint32_t bit = (uint32_t)__popc(e & bpost) & 1u;
@@ -206,47 +254,63 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
       double ar[16], ai[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const uint32_t off = (S[16 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
-        if (j < nreg) { const double2 v = tile[rbase ^ off]; ar[j] = v.x; ai[j] = v.y; }
-        else { ar[j] = 0.0; ai[j] = 0.0; }
+        const uint32_t off = (G[16 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
+        if (j < nreg && !(dbg & 2)) { const double2 v = tile[rbase ^ off]; ar[j] = v.x; ai[j] = v.y; }
+        else { ar[j] = (double)(rbase + j); ai[j] = 0.0; }
       }
       const uint32_t* __restrict__ Q = S + STAGE_HDR_WORDS;
       if (sflags & STAGE_SIGN_PRE) { apply_sign(Q, e, n, ar, ai); Q += SIGNQ_WORDS; }
-      if (fi[0] != 0xffffu) op_u1<0>(ar, ai, U[0]);
-      if (fi[1] != 0xffffu) op_u1<1>(ar, ai, U[1]);
-      if (fi[2] != 0xffffu) op_u1<2>(ar, ai, U[2]);
-      if (fi[3] != 0xffffu) op_u1<3>(ar, ai, U[3]);
+      if (!(dbg & 1)) {
+        if (fi[0] != 0xffffu) op_u1<0>(ar, ai, Us);
+        if (fi[1] != 0xffffu) op_u1<1>(ar, ai, Us + 4);
+        if (fi[2] != 0xffffu) op_u1<2>(ar, ai, Us + 8);
+        if (fi[3] != 0xffffu) op_u1<3>(ar, ai, Us + 12);
+      }
       if (sflags & STAGE_SIGN_POST) apply_sign(Q, e2, n, ar, ai);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const uint32_t off = (S[24 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
-        if (j < nreg) tile[wbase ^ off] = make_double2(ar[j], ai[j]);
+        const uint32_t off = (G[24 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
+        if (j < nreg && !(dbg & 2)) tile[wbase ^ off] = make_double2(ar[j], ai[j]);
+      }
+      if (dbg & 2) {   // timing-only build of the stage without LDS traffic: keep the values alive
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += ar[j] + ai[j];
+        if (acc == 1.2345e300) tile[0] = make_double2(acc, acc);
       }
     }
-    __syncthreads();
+    if (!(dbg & 16)) __syncthreads();
     S += nwords;
   }
 
   // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order ---------------
-  if (t < ksize) {
-    uint32_t gout = 0;
-    for (int m = 0; m < n - k; ++m) gout |= ((g >> m) & 1u) << P[PW_OUT_GPHYS + m];
-    const uint32_t thr_l = deposit_bits(t, 0, kt, P + PW_OUT_LDS);
-    const uint32_t thr_p = (t & ((1u << lo_out) - 1u)) | deposit_bits(t, lo_out, kt, P + PW_OUT_PHYS);
+  if (t < ksize && !(dbg & 8)) {
+    const uint32_t gout = deposit16(g, 0, n - k, out_gphys);
+    const uint32_t thr_l = deposit16(t, 0, kt, out_lds);
+    const uint32_t thr_p = (t & ((1u << lo_out) - 1u)) | deposit16(t, lo_out, kt, out_phys);
+    uint32_t lpos[4], ppos[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      lpos[m] = (kt + m < k) ? byte16(out_lds, (uint32_t)(kt + m)) : 0u;
+      ppos[m] = (kt + m < k) ? byte16(out_phys, (uint32_t)(kt + m)) : 0u;
+    }
     const bool fin = flags & PASS_FINAL;
     double2* __restrict__ dst = out + b * state_stride + gout;
     double* __restrict__ pdst = probs + (b << n) + gout;
-#pragma unroll 4
-    for (int i = 0; i < niter; ++i) {
-      uint32_t it_l = 0, it_p = 0;
-      for (int j = kt; j < k; ++j) {
-        const uint32_t bit = ((uint32_t)i >> (j - kt)) & 1u;
-        it_l |= bit << P[PW_OUT_LDS + j];
-        it_p |= bit << P[PW_OUT_PHYS + j];
-      }
+    auto move_out = [&](int i) {
+      const uint32_t it_l = ((i & 1) ? 1u << lpos[0] : 0u) | ((i & 2) ? 1u << lpos[1] : 0u) |
+                            ((i & 4) ? 1u << lpos[2] : 0u) | ((i & 8) ? 1u << lpos[3] : 0u);
+      const uint32_t it_p = ((i & 1) ? 1u << ppos[0] : 0u) | ((i & 2) ? 1u << ppos[1] : 0u) |
+                            ((i & 4) ? 1u << ppos[2] : 0u) | ((i & 8) ? 1u << ppos[3] : 0u);
       const double2 v = tile[lds_swizzle(thr_l | it_l)];
       if (fin) pdst[thr_p | it_p] = v.x * v.x + v.y * v.y;
       else dst[thr_p | it_p] = v;
+    };
+    if (FULL) {
+#pragma unroll
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) move_out(i);
+    } else {
+      for (int i = 0; i < niter; ++i) move_out(i);
     }
   }
 }
@@ -349,16 +413,27 @@ hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* th
 }
 
 hipError_t prepare_circuit_kernel(size_t lds_bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_kernel),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_kernel<false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, int batch,
                                const void* in, void* out, double* probs, const double* gates,
-                               long long gate_stride, hipStream_t st) {
+                               long long gate_stride, int dbg, hipStream_t st) {
   dim3 grid(1u << (n - k), (unsigned)batch);
-  circuit_pass_kernel<<<grid, dim3(threads), (size_t(1) << k) * 16, st>>>(
-      plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n);
+  int tau = 0;
+  while ((1 << tau) < threads) ++tau;
+  const bool full = (k - tau) == 4;   // 16 tile elements per thread
+  const size_t lds = (size_t(1) << k) * 16 + (size_t)MAX_STAGES * STAGE_MATS_BYTES;
+  if (full)
+    circuit_pass_kernel<true><<<grid, dim3(threads), lds, st>>>(
+        plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg);
+  else
+    circuit_pass_kernel<false><<<grid, dim3(threads), lds, st>>>(
+        plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg);
   return hipGetLastError();
 }
 

@@ -356,23 +356,25 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     const int lo_in = (int)P.in_low.size(), lo_out = (int)P.out_low.size();
     W[base + PW_FLAGS] = flags; W[base + PW_K] = k; W[base + PW_N] = n;
     W[base + PW_LO_IN] = lo_in; W[base + PW_LO_OUT] = lo_out; W[base + PW_THREADS] = threads;
+    auto put_byte = [&](int table, int j, int value) { W[base + table + (j >> 2)] |= (uint32_t)value << (8 * (j & 3)); };
+    if (k > 16 || n - k > 16) { msg = "tile or workgroup index wider than 16 bits"; return false; }
     for (int j = 0; j < k; ++j) {
       W[base + PW_WIRE_OF_LDS + j] = P.lds_wire[j];
-      W[base + PW_IN_PHYS + j] = (i > 0) ? layout[i - 1][P.lds_wire[j]] : (n - 1 - P.lds_wire[j]);
+      put_byte(PW_IN_PHYS, j, (i > 0) ? layout[i - 1][P.lds_wire[j]] : (n - 1 - P.lds_wire[j]));
     }
     for (int m = 0; m < n - k; ++m) {
       W[base + PW_WIRE_OF_G + m] = P.global[m];
-      W[base + PW_IN_GPHYS + m] = (i > 0) ? layout[i - 1][P.global[m]] : (n - 1 - P.global[m]);
-      W[base + PW_OUT_GPHYS + m] = layout[i][P.global[m]];
+      put_byte(PW_IN_GPHYS, m, (i > 0) ? layout[i - 1][P.global[m]] : (n - 1 - P.global[m]));
+      put_byte(PW_OUT_GPHYS, m, layout[i][P.global[m]]);
     }
     {  // out enumeration: out_low wires first (phys bit j), then the other local wires by LDS position
       std::vector<char> isl(n, 0);
       int j = 0;
-      for (int w : P.out_low) { W[base + PW_OUT_LDS + j] = ldspos[w]; W[base + PW_OUT_PHYS + j] = layout[i][w]; isl[w] = 1; ++j; }
+      for (int w : P.out_low) { put_byte(PW_OUT_LDS, j, ldspos[w]); put_byte(PW_OUT_PHYS, j, layout[i][w]); isl[w] = 1; ++j; }
       for (int q = 0; q < k; ++q) {
         int w = P.lds_wire[q];
         if (isl[w]) continue;
-        W[base + PW_OUT_LDS + j] = q; W[base + PW_OUT_PHYS + j] = layout[i][w]; ++j;
+        put_byte(PW_OUT_LDS, j, q); put_byte(PW_OUT_PHYS, j, layout[i][w]); ++j;
       }
     }
     // ---- stages ----
@@ -452,6 +454,9 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       for (int idx : sel.us) fidx[regbit[ops[idx].a]] = (uint32_t)ops[idx].idx;
       W[sbase + 6] = fidx[0] | (fidx[1] << 16);
       W[sbase + 7] = fidx[2] | (fidx[3] << 16);
+      if (nstages >= (uint32_t)MAX_STAGES) { msg = "too many stages in one pass"; return false; }
+      W[base + PW_MATS + 2 * nstages] = W[sbase + 6];
+      W[base + PW_MATS + 2 * nstages + 1] = W[sbase + 7];
       for (int t = 0; t < 4; ++t) { W[sbase + 8 + t] = t < r ? pre[t].bext : 0u; W[sbase + 12 + t] = t < r ? post[t].bext : 0u; }
       for (int j = 0; j < 16; ++j) {
         const uint32_t lo_ = (j < (1 << r)) ? lds_swizzle(slot_offset(pre, j)) : 0u;

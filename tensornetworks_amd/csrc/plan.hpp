@@ -46,18 +46,25 @@ enum PlanHeader : int {
 //   [0] wire  [1] n_elem  [2+2e] kind_e  [3+2e] param_e   (e < FUSED_MAX_ELEMS), applied e = 0 first
 constexpr int FUSED_MAX_ELEMS = 4;
 constexpr int FUSED_WORDS = 2 + 2 * FUSED_MAX_ELEMS;
-// pass descriptor
+// pass descriptor: a 32-word header the kernel fetches with two wide scalar loads; bit positions are
+// packed one per byte (16 bytes = 4 words per table, so k <= 16 and n - k <= 16)
 enum PassWords : int {
   PW_FLAGS = 0, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS, PW_RESERVED,
-  PW_IN_PHYS = 8,       // [32] phys-in bit position of LDS bit j
-  PW_IN_GPHYS = 40,     // [32] phys-in bit position of workgroup-index bit m
-  PW_OUT_LDS = 72,      // [32] LDS bit position of out-enumeration bit j
-  PW_OUT_PHYS = 104,    // [32] phys-out bit position of out-enumeration bit j
-  PW_OUT_GPHYS = 136,   // [32] phys-out bit position of workgroup-index bit m
-  PW_WIRE_OF_LDS = 168, // [32] wire held by LDS bit j        (informational / emulator)
-  PW_WIRE_OF_G = 200,   // [32] wire held by workgroup bit m  (informational / emulator)
-  PW_STAGES = 232
+  PW_IN_PHYS = 8,       // [16 bytes] phys-in bit position of LDS bit j
+  PW_IN_GPHYS = 12,     // [16 bytes] phys-in bit position of workgroup-index bit m
+  PW_OUT_LDS = 16,      // [16 bytes] LDS bit position of out-enumeration bit j
+  PW_OUT_PHYS = 20,     // [16 bytes] phys-out bit position of out-enumeration bit j
+  PW_OUT_GPHYS = 24,    // [16 bytes] phys-out bit position of workgroup-index bit m
+  PW_HEADER_WORDS = 32,
+  PW_WIRE_OF_LDS = 32,  // [32 words] wire held by LDS bit j        (informational / emulator)
+  PW_WIRE_OF_G = 64,    // [32 words] wire held by workgroup bit m  (informational / emulator)
+  PW_MATS = 96,         // [MAX_STAGES * 2 words] fused gate index of (stage s, register bit i), 16 bits each:
+                        //   word PW_MATS + 2 s + (i >> 1); the workgroup copies these matrices of ITS circuit
+                        //   into LDS (after the tile) while the tile loads are in flight
+  PW_STAGES = 96 + 2 * 32
 };
+constexpr int MAX_STAGES = 32;          // stages per pass
+constexpr int STAGE_MATS_BYTES = 4 * 64; // LDS bytes of one stage's four 2x2 complex matrices
 constexpr uint32_t PASS_INIT = 1u;   // tile starts as |0...0> (no HBM read)
 constexpr uint32_t PASS_FINAL = 2u;  // epilogue writes |psi|^2 in canonical order
 constexpr uint32_t PASS_FINAL_STATE = 4u;  // epilogue writes the state itself in canonical order
@@ -99,7 +106,7 @@ struct Plan {
   int n = 0, k = 0, r = 0, n_passes = 0, n_fused = 0, n_params = 0, threads = 0, n_gates = 0;
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;  // word offset of each pass descriptor
-  size_t lds_bytes() const { return (size_t(1) << k) * 16; }
+  size_t lds_bytes() const { return (size_t(1) << k) * 16 + (size_t)MAX_STAGES * STAGE_MATS_BYTES; }
 };
 
 // Returns false (with msg) on unsupported sizes.

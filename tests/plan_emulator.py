@@ -13,7 +13,8 @@ from oracle import circuit as oc
 PH_N, PH_K, PH_NPASSES, PH_NFUSED, PH_NPARAMS, PH_OFF_FUSED, PH_OFF_PASSTAB, PH_TOTAL, PH_THREADS, PH_R, PH_NGATES = range(1, 12)
 FUSED_WORDS = 10
 PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
-PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_LDS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_STAGES = 8, 40, 72, 104, 136, 168, 200, 232
+PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_LDS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_STAGES = 8, 12, 16, 20, 24, 32, 64, 160
+PW_MATS = 96
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
 STAGE_HDR_WORDS = 32
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
@@ -33,6 +34,11 @@ def fused_matrices(W, theta):
             U = oc.matrix_1q(KIND_NAMES[kind], t) @ U
         mats.append(U)
     return mats
+
+
+def tbyte(P, table, j):
+    """Entry j of a byte-packed 16-entry table of the pass header."""
+    return (int(P[table + (j >> 2)]) >> (8 * (j & 3))) & 0xFF
 
 
 def swz(l):
@@ -78,9 +84,9 @@ def run_plan(W, mats, state_in=None):
         probs = np.zeros(N)
         # structural checks the kernel relies on
         for j in range(lo_in):
-            assert (flags & PASS_INIT) or int(P[PW_IN_PHYS + j]) == j
+            assert (flags & PASS_INIT) or tbyte(P, PW_IN_PHYS, j) == j
         for j in range(lo_out):
-            assert int(P[PW_OUT_PHYS + j]) == j
+            assert tbyte(P, PW_OUT_PHYS, j) == j
         for g in range(1 << (n - k)):
             u = np.arange(ksize, dtype=np.int64)
             if flags & PASS_INIT:
@@ -90,12 +96,14 @@ def run_plan(W, mats, state_in=None):
             else:
                 phys = np.zeros(ksize, dtype=np.int64)
                 for j in range(k):
-                    phys |= ((u >> j) & 1) << int(P[PW_IN_PHYS + j])
+                    phys |= ((u >> j) & 1) << tbyte(P, PW_IN_PHYS, j)
                 for m in range(n - k):
-                    phys |= ((g >> m) & 1) << int(P[PW_IN_GPHYS + m])
+                    phys |= ((g >> m) & 1) << tbyte(P, PW_IN_GPHYS, m)
                 tile = buf[phys]
             S = P[PW_STAGES:]
-            for _ in range(nst):
+            for si in range(nst):
+                # the per-pass matrix table (what the kernel stages into LDS) must agree with the stage header
+                assert int(P[PW_MATS + 2 * si]) == int(S[6]) and int(P[PW_MATS + 2 * si + 1]) == int(S[7])
                 hdr = int(S[0]); r = hdr & 0xFF; sflags = (hdr >> 8) & 0xFF; nwords = hdr >> 16
                 rho = int(S[1])
                 nthr = 1 << (k - r)
@@ -158,10 +166,10 @@ def run_plan(W, mats, state_in=None):
             lds = np.zeros(ksize, dtype=np.int64)
             phys = np.zeros(ksize, dtype=np.int64)
             for j in range(k):
-                lds |= ((v >> j) & 1) << int(P[PW_OUT_LDS + j])
-                phys |= ((v >> j) & 1) << int(P[PW_OUT_PHYS + j])
+                lds |= ((v >> j) & 1) << tbyte(P, PW_OUT_LDS, j)
+                phys |= ((v >> j) & 1) << tbyte(P, PW_OUT_PHYS, j)
             for m in range(n - k):
-                phys |= ((g >> m) & 1) << int(P[PW_OUT_GPHYS + m])
+                phys |= ((g >> m) & 1) << tbyte(P, PW_OUT_GPHYS, m)
             assert np.array_equal(np.sort(lds), np.arange(ksize))
             if flags & PASS_FINAL:
                 probs[phys] = np.abs(tile[lds]) ** 2
