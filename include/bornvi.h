@@ -155,6 +155,14 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
                           double* ksd2, double* Y, void* workspace, size_t workspace_bytes,
                           bornvi_stream stream);
 
+/* Same result for a SYMMETRIC K (every K from bornvi_stein_gram_build is bitwise symmetric): reads
+ * only the upper triangle, i.e. half the HBM traffic of bornvi_stein_quadform; deterministic (column
+ * partials in the workspace instead of atomics).  q, y dev [2^n]; ksd2 dev [1]. */
+size_t bornvi_stein_quadform_sym_workspace_bytes(bornvi_handle h, int n);
+int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const double* q,
+                              double* ksd2, double* y, void* workspace, size_t workspace_bytes,
+                              bornvi_stream stream);
+
 /* Row-sharded form: K_rows holds rows [row_begin, row_end); q dev [2^n] (full);
  * y_rows dev [row_end - row_begin] = those rows of K q (or NULL); ksd2_partial dev [1] =
  * sum over them of q_i y_i.  Workspace as bornvi_stein_quadform. */

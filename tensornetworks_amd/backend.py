@@ -227,6 +227,20 @@ def stein_quadform(K, Q, n, want_y=True):
     return ksd2, Y
 
 
+def stein_quadform_sym(K, q, n):
+    """(ksd2 [1], y = K q [2^n]) for a symmetric K (as built by stein_gram): reads the upper triangle only."""
+    dev = K.device
+    h = _ext.handle_for(dev)
+    _chk(K, torch.float64, dev, "K")
+    _chk(q, torch.float64, dev, "q")
+    y = torch.empty(1 << n, dtype=torch.float64, device=dev)
+    ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
+    ws = _ws(dev, h.size("bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
+    h.call("bornvi_stein_quadform_sym", n, _ptr(K), _ptr(q), _ptr(ksd2), _ptr(y), _ptr(ws), ws.numel(),
+           _ext.stream_ptr(dev))
+    return ksd2, y
+
+
 def stein_matvec_kron(S, q, n, length_scale=1.0):
     """Matrix-free (ksd2 [1], y = K_p q [2^n])."""
     dev = S.device

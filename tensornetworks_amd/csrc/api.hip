@@ -344,6 +344,24 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
   return BORNVI_OK;
 }
 
+size_t bornvi_stein_quadform_sym_workspace_bytes(bornvi_handle h, int n) {
+  (void)h;
+  if (!valid_n_for_dense(n)) return 0;
+  return align_up(quadform_sym_workspace_doubles(n) * sizeof(double), 256);
+}
+
+int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const double* q, double* ksd2, double* y,
+                              void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!K || !q || !ksd2) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
+    return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_quadform_sym(n, K, q, y, ksd2, (double*)workspace, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
 size_t bornvi_stein_matvec_kron_workspace_bytes(bornvi_handle h, int n) {
   if (!h || n < 1 || n > 30) return 0;
   DevPlan* dp = nullptr;

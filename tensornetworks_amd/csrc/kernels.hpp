@@ -31,6 +31,9 @@ hipError_t launch_kp_pairs(int n, double length_scale, long long M, const long l
 size_t quadform_partials(long long rows);  // number of per-workgroup partial sums
 hipError_t launch_quadform(int n, const double* K, long long row_begin, long long row_end, const double* q,
                            double* y_or_null, double* ksd2, double* partials, hipStream_t st);
+size_t quadform_sym_workspace_doubles(int n);
+hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2, double* ws,
+                               hipStream_t st);
 // matrix-free mat-vec helpers
 hipError_t launch_kron_pack(int n, double length_scale, const double* S, const double* q,
                             double* packed /*complex [(n+2)/2, 2^n]*/, double* gate /*[8]*/, hipStream_t st);

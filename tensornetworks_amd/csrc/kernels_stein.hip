@@ -277,6 +277,125 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 }
 
 // ------------------------------------------------------------------------------------------------
+// symmetric quadratic form: K_p is symmetric (gram_kernel evaluates every entry symmetrically, so it
+// is BITWISE symmetric), hence y = K q needs only the upper triangle: half the HBM traffic.
+// One wave owns a strip of SYM_ROWS rows [i0, i0 + SYM_ROWS) and sweeps the columns j >= i0:
+//   row part   yrow[i] = sum_{j >= i0} K_ij q_j                      (registers, wave-reduced at the end)
+//   column part Z_s[j] = sum_{i in strip} K_ij q_i  for j >= i0 + SYM_ROWS (one 16-byte store per lane
+//               and 128-column chunk; strip s keeps N - (s+1) SYM_ROWS entries)
+// then y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j] in a second kernel.  No atomics: fixed summation order.
+// Traffic: 8 * N^2 / 2 (+ one diagonal block per strip) + 2 * 8 * N^2 / (2 SYM_ROWS) bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int SYM_ROWS = 32;
+
+__device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
+  return s * N - (long long)SYM_ROWS * (s * (s + 1) / 2);   // Z_s[j - (s+1) SYM_ROWS] lives at this base
+}
+
+__global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restrict__ K, const double* __restrict__ q,
+                                                           double* __restrict__ yrow, double* __restrict__ Z, long long N) {
+  const int lane = threadIdx.x & 63;
+  // strip = wave; readfirstlane makes the wave index provably uniform, so q_i of the strip and all
+  // row addresses live in scalar registers
+  const long long s = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
+  if (s >= nstrips) return;
+  // heavy (long) strips first would need a remap; dispatch order already interleaves them over the CUs
+  const long long i0 = s * SYM_ROWS;
+  const int nrows = (int)((N - i0 < SYM_ROWS) ? N - i0 : SYM_ROWS);
+  double qi[SYM_ROWS];
+#pragma unroll
+  for (int r = 0; r < SYM_ROWS; ++r) qi[r] = (r < nrows) ? q[i0 + r] : 0.0;
+  double acc[SYM_ROWS];
+#pragma unroll
+  for (int r = 0; r < SYM_ROWS; ++r) acc[r] = 0.0;
+  double* __restrict__ Zs = Z + sym_z_offset(s, N) - (i0 + SYM_ROWS);   // so that Zs[j] is the entry of column j
+  const double* __restrict__ Kr = K + i0 * N;
+  for (long long c = (i0 / 128) * 128 + lane * 2; c < N; c += 128) {
+    const bool in_tri = c >= i0;                  // i0 and SYM_ROWS are even: both columns of a lane agree
+    const bool off_diag = c >= i0 + SYM_ROWS;
+    if (!in_tri) continue;
+    const double2 q2 = *reinterpret_cast<const double2*>(q + c);
+    double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+    for (int r0 = 0; r0 < SYM_ROWS; r0 += 8) {
+      double2 kv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double* p = Kr + (long long)(r0 + u) * N + c;
+        if (r0 + u < nrows) { kv[u].x = __builtin_nontemporal_load(p); kv[u].y = __builtin_nontemporal_load(p + 1); }
+        else { kv[u].x = 0.0; kv[u].y = 0.0; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc[r0 + u] = fma(kv[u].x, q2.x, fma(kv[u].y, q2.y, acc[r0 + u]));
+        z0 = fma(kv[u].x, qi[r0 + u], z0);
+        z1 = fma(kv[u].y, qi[r0 + u], z1);
+      }
+    }
+    if (off_diag) *reinterpret_cast<double2*>(Zs + c) = make_double2(z0, z1);
+  }
+#pragma unroll
+  for (int r = 0; r < SYM_ROWS; ++r) {
+    const double v = wave_sum(acc[r]);
+    if (lane == 0 && r < nrows) yrow[i0 + r] = v;
+  }
+}
+
+// y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j]; 64 columns per workgroup, the strips dealt to 4 waves and
+// combined through LDS in wave order; also the per-workgroup partial of q . y.
+__global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* __restrict__ yrow, const double* __restrict__ Z,
+                                                                  const double* __restrict__ q, double* __restrict__ y,
+                                                                  double* __restrict__ partials, long long N) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long j = (long long)blockIdx.x * 64 + lane;
+  double acc = 0.0;
+  if (j < N) {
+    const long long ns = j / SYM_ROWS;              // strips strictly above column j's own strip
+    for (long long s = wave; s < ns; s += 4)
+      acc += Z[sym_z_offset(s, N) + (j - (s + 1) * SYM_ROWS)];
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    double v = 0.0, contrib = 0.0;
+    if (j < N) {
+      v = yrow[j] + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+      if (y) y[j] = v;
+      contrib = q[j] * v;
+    }
+    contrib = wave_sum(contrib);
+    if (lane == 0) partials[blockIdx.x] = contrib;
+  }
+}
+
+size_t quadform_sym_workspace_doubles(int n) {
+  const long long N = 1ll << n;
+  const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
+  const long long z = ns * N - (long long)SYM_ROWS * (ns * (ns + 1) / 2) + 2 * SYM_ROWS;   // all strips (+ slack)
+  return (size_t)(z > 0 ? z : 0) + (size_t)N /*yrow*/ + (size_t)((N + 63) / 64) /*partials*/ + 64;
+}
+
+hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
+                               double* ws, hipStream_t st) {
+  const long long N = 1ll << n;
+  const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
+  double* yrow = ws;
+  double* partials = ws + N;
+  const long long nred = (N + 63) / 64;
+  double* Z = partials + ((nred + 31) / 32) * 32;          // keep Z 16-byte aligned (N, offsets are even)
+  quadform_sym_kernel<<<(unsigned)((ns + 3) / 4), 256, 0, st>>>(K, q, yrow, Z, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z, q, y_or_null, partials, N);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  sum_partials_kernel<<<1, 256, 0, st>>>(partials, nred, ksd2);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // matrix-free y = K_p q.  The n+1 real vectors v_0 = q, v_{b+1} = s_b o q
 // are packed two per complex128 state, pushed through K_base = M^{(x) n} by the circuit pass engine
 // (real 2x2 butterflies act on re and im independently), then combined:

@@ -105,6 +105,7 @@ class KSDVariationalInference:
         self._K_rows = None     # (row_begin, row_end) held in self._K
         self._stein_key = None
         self.timers = None      # optional {name: [(start_event, end_event), ...]} filled by ksd_and_grad
+        self.symmetric_contraction = True   # dense mode: contract with the upper triangle of K_p only
 
     # ---- reference attribute kept lazily (2^n Python tuples) -------------------------------------------
     @property
@@ -168,6 +169,8 @@ class KSDVariationalInference:
         rank, ws = shard.world(self.process_group)
         r0, r1 = self._K_rows
         if ws == 1:
+            if self.symmetric_contraction:      # K_p from our builder is bitwise symmetric: read half of it
+                return backend.stein_quadform_sym(self._K, q, n)
             ksd2, Y = backend.stein_quadform(self._K, q, n, want_y=True)
             return ksd2, Y[0]
         # row shard: every rank contributes its rows of K q plus its partial of q.y in one all-gather

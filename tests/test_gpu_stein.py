@@ -103,6 +103,24 @@ def test_quadform_and_kron_match_oracle(be, dev, n, seed):
     np.testing.assert_array_equal(k_only.cpu().numpy(), ksd2.cpu().numpy())
 
 
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 8, 10, 12])
+def test_symmetric_quadform_equals_full(be, dev, n):
+    """Upper-triangle contraction == full-matrix contraction (K_p is bitwise symmetric)."""
+    bn, lat, obs, x = synthetic_network(n, 1)
+    S, _ = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    K = be.stein_gram(S, n, 1.0)
+    g = torch.Generator().manual_seed(n)
+    q = torch.rand(2 ** n, generator=g, dtype=torch.float64).to(dev)
+    q /= q.sum()
+    k_full, Y = be.stein_quadform(K, q, n)
+    k_sym, y_sym = be.stein_quadform_sym(K, q, n)
+    scale = (K.abs() @ q).max().item()
+    assert (Y[0] - y_sym).abs().max().item() <= 1e-13 * scale
+    assert abs(k_full.item() - k_sym.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
+    # the reference value: dense NumPy product
+    np.testing.assert_allclose(y_sym.cpu().numpy(), K.cpu().numpy() @ q.cpu().numpy(), rtol=0, atol=1e-13 * scale)
+
+
 def test_length_scale(be, dev):
     g = golden("synthetic_n5_s0.npz")
     S = torch.as_tensor(g["S"], device=dev)
@@ -174,6 +192,9 @@ def test_full_size_gram_properties(be, dev):
     q = torch.rand(2 ** n, generator=g, dtype=torch.float64).to(dev)
     q /= q.sum()
     k2d, yd = be.stein_quadform(K, q, n)
+    k2s, ys = be.stein_quadform_sym(K, q, n)
+    assert abs(k2d.item() - k2s.item()) <= 1e-12 * abs(k2d.item())
+    assert (yd[0] - ys).abs().max().item() <= 1e-12 * yd.abs().max().item()
     k2k, yk = be.stein_matvec_kron(S, q, n, 1.0)
     assert abs(k2d.item() - k2k.item()) <= 1e-9 * abs(k2d.item())
     assert (yd[0] - yk).abs().max().item() <= 1e-10 * yd.abs().max().item()
