@@ -292,15 +292,10 @@ __device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
   return s * N - (long long)SYM_ROWS * (s * (s + 1) / 2);   // Z_s[j - (s+1) SYM_ROWS] lives at this base
 }
 
-__global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restrict__ K, const double* __restrict__ q,
-                                                           double* __restrict__ yrow, double* __restrict__ Z, long long N) {
-  const int lane = threadIdx.x & 63;
-  // strip = wave; readfirstlane makes the wave index provably uniform, so q_i of the strip and all
-  // row addresses live in scalar registers
-  const long long s = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
-  if (s >= nstrips) return;
-  // heavy (long) strips first would need a remap; dispatch order already interleaves them over the CUs
+// one strip: rows [s SYM_ROWS, (s+1) SYM_ROWS), columns >= s SYM_ROWS
+__device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ K, const double* __restrict__ q,
+                                                   double* __restrict__ yrow, double* __restrict__ Z, long long N,
+                                                   long long s, int lane) {
   const long long i0 = s * SYM_ROWS;
   const int nrows = (int)((N - i0 < SYM_ROWS) ? N - i0 : SYM_ROWS);
   double qi[SYM_ROWS];
@@ -311,6 +306,7 @@ __global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restr
   for (int r = 0; r < SYM_ROWS; ++r) acc[r] = 0.0;
   double* __restrict__ Zs = Z + sym_z_offset(s, N) - (i0 + SYM_ROWS);   // so that Zs[j] is the entry of column j
   const double* __restrict__ Kr = K + i0 * N;
+#pragma unroll 1
   for (long long c = (i0 / 128) * 128 + lane * 2; c < N; c += 128) {
     const bool in_tri = c >= i0;                  // i0 and SYM_ROWS are even: both columns of a lane agree
     const bool off_diag = c >= i0 + SYM_ROWS;
@@ -340,6 +336,21 @@ __global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restr
     const double v = wave_sum(acc[r]);
     if (lane == 0 && r < nrows) yrow[i0 + r] = v;
   }
+}
+
+// wave w owns strips w and nstrips-1-w: a long and a short one, so every wave streams ~N + SYM_ROWS columns
+__global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restrict__ K, const double* __restrict__ q,
+                                                           double* __restrict__ yrow, double* __restrict__ Z, long long N) {
+  const int lane = threadIdx.x & 63;
+  // readfirstlane makes the wave index provably uniform, so q_i of the strip and all row addresses live
+  // in scalar registers
+  const long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
+  const long long npairs = (nstrips + 1) / 2;
+  if (w >= npairs) return;
+  quadform_sym_strip(K, q, yrow, Z, N, w, lane);
+  const long long s2 = nstrips - 1 - w;
+  if (s2 != w) quadform_sym_strip(K, q, yrow, Z, N, s2, lane);
 }
 
 // y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j]; 64 columns per workgroup, the strips dealt to 4 waves and
@@ -385,7 +396,8 @@ hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* 
   double* partials = ws + N;
   const long long nred = (N + 63) / 64;
   double* Z = partials + ((nred + 31) / 32) * 32;          // keep Z 16-byte aligned (N, offsets are even)
-  quadform_sym_kernel<<<(unsigned)((ns + 3) / 4), 256, 0, st>>>(K, q, yrow, Z, N);
+  const long long npairs = (ns + 1) / 2;
+  quadform_sym_kernel<<<(unsigned)((npairs + 3) / 4), 256, 0, st>>>(K, q, yrow, Z, N);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z, q, y_or_null, partials, N);
