@@ -183,7 +183,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)
+        plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)   # same defaults as the handle
         n_passes, n_gates = int(plan[3]), int(plan[11])
         lo, hi = (0, P) if world == 1 else (0, -(-P // world))
         circuits_rank = 1 + 2 * (hi - lo)

@@ -60,8 +60,10 @@ void bornvi_destroy(bornvi_handle h);
 const char* bornvi_last_error(bornvi_handle h);
 
 /* Tuning knobs of the circuit planner (clears the plan cache): "tile_bits" (4..13, amplitudes per
- * LDS tile = 2^tile_bits), "low_bits" (0..8, contiguous 16-byte elements per HBM run = 2^low_bits),
- * "max_threads" (64..512). */
+ * LDS tile = 2^tile_bits, for every n), "tile_bits_multi" (tile size used only when the state needs
+ * several tiles; default 12), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
+ * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
+ * results are INVALID while non-zero). */
 int bornvi_set_option(bornvi_handle h, const char* name, long long value);
 
 /* num_ansatz_params (quantum_born_machine.py:31-38) and gate count of the QNode. */

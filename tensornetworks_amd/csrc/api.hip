@@ -169,11 +169,12 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   if (!h || !name) return BORNVI_ERR_INVALID;
   if (!std::strcmp(name, "debug_flags")) { h->debug_flags = (int)value; return BORNVI_OK; }
   PlanOptions o = h->opt;
-  if (!std::strcmp(name, "tile_bits")) o.kmax = (int)value;
+  if (!std::strcmp(name, "tile_bits")) { o.kmax = (int)value; o.kmulti = (int)value; }
+  else if (!std::strcmp(name, "tile_bits_multi")) o.kmulti = (int)value;
   else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;
   else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
   else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
-  if (o.kmax < 4 || o.kmax > 13 || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
+  if (o.kmax < 4 || o.kmax > 13 || o.kmulti < 4 || o.kmulti > 13 || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
       (o.max_threads & (o.max_threads - 1)))
     return fail(h, BORNVI_ERR_INVALID, "option value out of range");
   h->opt = o;
@@ -417,7 +418,7 @@ int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_
 
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
   PlanOptions opt;
-  if (tile_bits > 0) opt.kmax = tile_bits;
+  if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
   Plan p;
   std::string msg;
   const bool ok = (ansatz == -1) ? make_kron_plan(n, opt, p, msg) : make_plan(ansatz, n, layers, opt, p, msg);

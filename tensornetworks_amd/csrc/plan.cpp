@@ -240,7 +240,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
   const int n = spec.n;
   const std::vector<Op>& ops = spec.ops;
   const std::vector<Fused>& fused = spec.fused;
-  const int k = std::min(n, opt.kmax);
+  const int k = (n <= opt.kmax) ? n : std::min(opt.kmax, opt.kmulti);
   const int r = std::min(opt.r, k);
   if (r > 4) { msg = "at most 4 register wires"; return false; }
   int threads = 64;

@@ -96,7 +96,9 @@ constexpr int SIGNQ_WORDS = 49;
 BORNVI_HD inline uint32_t lds_swizzle(uint32_t l) { return l ^ (((l >> 4) ^ (l >> 8) ^ (l >> 12)) & 15u); }
 
 struct PlanOptions {
-  int kmax = 13;     // tile bits (2^13 complex128 = 128 KiB of LDS)
+  int kmax = 13;     // largest tile (2^13 complex128 = 128 KiB of LDS): a state of n <= kmax qubits is ONE tile
+  int kmulti = 12;   // tile bits when the state needs several tiles (n > kmax): 64 KiB tiles let two
+                     // workgroups share a CU, so one's HBM phases overlap the other's LDS/FMA phases
   int r = 4;         // register wires per stage (2^4 amplitudes per thread)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 512;
