@@ -192,23 +192,42 @@ def main():
         # algorithmic bytes: 32 * 2^n per gate per state; dense contraction 8 * 4^n
         circ_bytes = 32.0 * N * n_gates * circuits_rank
         rows_rank = -(-N // world)
+        sym = gram_mode == "dense" and world == 1 and vi.symmetric_contraction
+        stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
         stein_bytes = 8.0 * N * rows_rank if gram_mode == "dense" else 16.0 * N * n * (n + 1)
+        # real HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.sh), recorded
+        # for the default workload only
+        pmc = {}
+        pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic_n16_L6_dense.json")
+        if args.workload == "n16_L6_dense" and world == 1 and not args.tile_bits and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))["kernels"]
+        t_circ = pmc.get("circuit_pass_kernel<true>", {}).get("hbm_bytes_per_launch")
+        t_stein = None
+        if sym and "quadform_sym_kernel" in pmc:
+            t_stein = pmc["quadform_sym_kernel"]["hbm_bytes_per_launch"] + pmc["quadform_sym_reduce_kernel"]["hbm_bytes_per_launch"]
         kern = {
             "circuit_pass_kernel": {"bound": "hbm", "launches_per_step": n_passes,
                                     "achieved": round(circ_bytes / (circ_ms * 1e-3) / 1e9, 1) if circ_ms else None,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_ms, 4),
                                     "avg_launch_ms": round(circ_ms / n_passes, 4),
-                                    "algorithmic_bytes_per_step": circ_bytes, "traffic": None,
-                                    "note": "gate-apply accounting: un-fused bytes; passes keep the state in LDS, so "
-                                            "achieved may exceed the HBM peak (real traffic: profiles/)"},
-            ("quadform_kernel" if gram_mode == "dense" else "kron_matvec"): {
+                                    "algorithmic_bytes_per_launch": circ_bytes / n_passes, "traffic": t_circ,
+                                    "note": "achieved = SURVEY 8(d) un-fused accounting (32 * 2^n bytes per gate per state); the "
+                                            "fused engine keeps the state in LDS across a pass, so it exceeds the HBM peak; "
+                                            "traffic = measured HBM bytes per launch (PMC)"},
+            stein_name: {
                 "bound": "hbm", "launches_per_step": 1,
                 "achieved": round(stein_bytes / (stein_ms * 1e-3) / 1e9, 1) if stein_ms else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(stein_ms, 4),
-                "avg_launch_ms": round(stein_ms, 4), "algorithmic_bytes_per_step": stein_bytes, "traffic": None},
+                "avg_launch_ms": round(stein_ms, 4), "algorithmic_bytes_per_launch": stein_bytes, "traffic": t_stein,
+                "note": ("achieved = SURVEY 8(d) accounting (8 * 4^n bytes); K_p is symmetric and only its upper triangle "
+                         "is read, so it exceeds the HBM peak; traffic = measured HBM bytes (PMC)") if sym else None},
         }
         for v in kern.values():
             v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
+            if v["traffic"]:
+                per_step = v["traffic"] * v["launches_per_step"]
+                v["traffic_gbs"] = round(per_step / (v["ms_per_step"] * 1e-3) / 1e9, 1)
+                v["traffic_frac"] = round(v["traffic_gbs"] / v["peak"], 4)
         dom_name = max(kern, key=lambda k_: kern[k_]["ms_per_step"])
         roof = dict(kern[dom_name])
         roof["kernel"] = dom_name

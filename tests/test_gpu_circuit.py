@@ -25,7 +25,8 @@ def dev():
 def be(dev):
     from tensornetworks_amd import backend
     yield backend
-    backend.set_option(dev, "tile_bits", 13)
+    backend.set_option(dev, "tile_bits", 13)          # restore the planner defaults
+    backend.set_option(dev, "tile_bits_multi", 12)
 
 
 def gpu_probs(be, dev, ansatz, n, L, thetas):
