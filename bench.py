@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-gate-bench", action="store_true")
     ap.add_argument("--tile-bits", type=int, default=0)
     ap.add_argument("--debug-flags", type=int, default=0, help="timing-only kernel ablations (results invalid)")
+    ap.add_argument("--overlap", type=int, default=-1, help="1/0: contraction on a second stream beside the shifted circuits")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,11 +125,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev)     # (several ranks may share a GPU in a rehearsal)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
+    dist_backend = os.environ.get("BORNVI_DIST_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing one GPU
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(dist_backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -145,6 +151,8 @@ def main():
     torch.manual_seed(0)
     vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,
                                  qbm_ansatz_type=ansatz, pytorch_device=str(dev), gram_mode=gram_mode)
+    if args.overlap >= 0:
+        vi.overlap_streams = bool(args.overlap)
     g = torch.Generator().manual_seed(0)
     P = vi.born_machine.num_ansatz_params
     with torch.no_grad():     # theta0 = 0.1 * randn(P) float32, `small_random` (quantum_born_machine.py:43-45)
@@ -178,7 +186,7 @@ def main():
     timers = vi.timers
     vi.timers = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -224,7 +232,7 @@ def main():
         }
         for v in kern.values():
             v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
-            if v["traffic"]:
+            if v["traffic"] and v["ms_per_step"]:
                 per_step = v["traffic"] * v["launches_per_step"]
                 v["traffic_gbs"] = round(per_step / (v["ms_per_step"] * 1e-3) / 1e9, 1)
                 v["traffic_frac"] = round(v["traffic_gbs"] / v["peak"], 4)
@@ -241,6 +249,7 @@ def main():
                        "params": P, "circuits_per_step": 1 + 2 * P, "gates_per_circuit": n_gates,
                        "gram": gram_mode, "bayesian_network": f"synthetic n={n} seed=0 (SURVEY 8d)",
                        "optimizer": "adam lr=0.005 cosine clip=10", "parallelism": f"paramshift+gram-rows shard x{world}",
+                       "dist_backend": dist_backend if world > 1 else None,
                        "tile_bits": int(plan[2]), "passes": n_passes},
             "roofline": roof, "kernels": kern,
             "phase_ms": {"circuits": round(circ_ms, 4), "stein": round(stein_ms, 4), "finish": round(fin_ms, 4)},

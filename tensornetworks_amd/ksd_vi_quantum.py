@@ -106,6 +106,9 @@ class KSDVariationalInference:
         self._stein_key = None
         self.timers = None      # optional {name: [(start_event, end_event), ...]} filled by ksd_and_grad
         self.symmetric_contraction = True   # dense mode: contract with the upper triangle of K_p only
+        self.overlap_streams = None         # contraction on a second stream beside the shifted circuits:
+                                            # None = only where it pays (dense Gram, n >= 14), True / False = forced
+        self._aux_stream = None
 
     # ---- reference attribute kept lazily (2^n Python tuples) -------------------------------------------
     @property
@@ -180,7 +183,7 @@ class KSDVariationalInference:
         msg[: r1 - r0] = part[:-1]
         msg[chunk] = part[-1]
         full = torch.empty((ws, chunk + 1), dtype=torch.float64, device=q.device)
-        torch.distributed.all_gather_into_tensor(full.view(-1), msg, group=self.process_group)
+        shard.all_gather_flat(full.view(-1), msg, self.process_group)
         y = full[:, :chunk].reshape(-1)[: 1 << n].contiguous()
         ksd2 = full[:, chunk].sum().reshape(1)      # fixed rank order: identical on every rank
         return ksd2, y
@@ -197,13 +200,41 @@ class KSDVariationalInference:
         P = theta64.numel()
         rank, ws = shard.world(self.process_group)
         lo, hi = shard.shard_range(P, rank, ws)
-        with self._timed("circuits"):
-            probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True)
-        q = probs[0]
-        with self._timed("stein"):
-            ksd2, y = self._stein_contract(q)
+        overlap = self.overlap_streams
+        if overlap is None:
+            overlap = self._K is not None and n >= 14
+        if not overlap:
+            with self._timed("circuits"):
+                probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True)
+            q = probs[0]
+            shifted = probs[1:]
+            with self._timed("stein"):
+                ksd2, y = self._stein_contract(q)
+        else:
+            # The contraction needs only q of the base circuit, the shifted circuits need neither: run the
+            # base circuit first, then the contraction on a second HIP stream while the 2P shifted circuits
+            # run on the main one (they are bound by different resources: HBM vs LDS/FMA + HBM).
+            main = torch.cuda.current_stream(dev)
+            if self._aux_stream is None:
+                self._aux_stream = torch.cuda.Stream(device=dev)
+            aux = self._aux_stream
+            with self._timed("circuits"):
+                q = backend.paramshift_probs(at, n, L, theta64, 0, 0, include_base=True)[0]
+                base_done = torch.cuda.Event()
+                base_done.record(main)
+                shifted = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=False)
+            with torch.cuda.stream(aux):
+                aux.wait_event(base_done)
+                with self._timed("stein"):
+                    ksd2, y = self._stein_contract(q)
+                stein_done = torch.cuda.Event()
+                stein_done.record(aux)
+            main.wait_event(stein_done)
+            for tns in (ksd2, y):
+                tns.record_stream(main)
+            q.record_stream(aux)
         with self._timed("finish"):
-            loss, grad_local, _ = backend.ksd_grad_finish(n, probs[1:], hi - lo, y, ksd2)
+            loss, grad_local, _ = backend.ksd_grad_finish(n, shifted, hi - lo, y, ksd2)
             grad = shard.all_gather_grad(grad_local, P, self.process_group)
         return loss, grad, q
 

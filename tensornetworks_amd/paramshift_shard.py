@@ -30,6 +30,20 @@ def shard_range(num_params, rank, world_size):
     return lo, hi
 
 
+def all_gather_flat(out, msg, group=None):
+    """all_gather_into_tensor for equal-sized float64 messages.  With the 'nccl' backend (RCCL) the device
+    tensors go straight onto xGMI; a 'gloo' group (CPU rehearsal, or several ranks sharing one GPU) stages
+    the few KB through host memory."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and msg.is_cuda:
+        out_h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(out_h, msg.cpu(), group=group)
+        out.copy_(out_h)
+    else:
+        dist.all_gather_into_tensor(out, msg, group=group)
+    return out
+
+
 def all_gather_grad(local_grad, num_params, group=None):
     """local_grad: this rank's slice (float64, any device the backend supports) -> full [P] vector,
     identical on every rank."""
@@ -40,5 +54,5 @@ def all_gather_grad(local_grad, num_params, group=None):
     padded = torch.zeros(chunk, dtype=local_grad.dtype, device=local_grad.device)
     padded[: local_grad.numel()] = local_grad
     full = torch.empty(chunk * ws, dtype=local_grad.dtype, device=local_grad.device)
-    dist.all_gather_into_tensor(full, padded, group=group)
+    all_gather_flat(full, padded, group)
     return full[:num_params]
