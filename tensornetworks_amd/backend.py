@@ -87,7 +87,7 @@ def circuit_probs(ansatz_type, n, layers, thetas):
     return probs
 
 
-def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=True, out=None):
+def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=True, out=None, ws_tag="main"):
     """theta float64 [P] -> probs [(1 if include_base) + 2 (p_end - p_begin), 2^n]:
     optional base row, then (+p, -p) rows for p in [p_begin, p_end)."""
     dev = theta.device
@@ -104,7 +104,7 @@ def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base
     if B == 0:
         return out
     need = h.size("bornvi_circuit_workspace_bytes", aid, n, layers, B)
-    ws = _ws(dev, min(need, max(WORKSPACE_CAP, h.size("bornvi_circuit_workspace_bytes", aid, n, layers, 1))))
+    ws = _ws(dev, min(need, max(WORKSPACE_CAP, h.size("bornvi_circuit_workspace_bytes", aid, n, layers, 1))), ws_tag)
     h.call("bornvi_paramshift_probs", aid, n, layers, _ptr(theta), int(p_begin), int(p_end),
            1 if include_base else 0, _ptr(out), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
     return out

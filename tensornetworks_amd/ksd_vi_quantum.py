@@ -211,28 +211,28 @@ class KSDVariationalInference:
             with self._timed("stein"):
                 ksd2, y = self._stein_contract(q)
         else:
-            # The contraction needs only q of the base circuit, the shifted circuits need neither: run the
-            # base circuit first, then the contraction on a second HIP stream while the 2P shifted circuits
-            # run on the main one (they are bound by different resources: HBM vs LDS/FMA + HBM).
+            # The contraction needs only q of the base circuit, the shifted circuits need neither: the base
+            # circuit and then the contraction run on a second HIP stream while the 2P shifted circuits run on
+            # the main one (they are bound by different resources: HBM vs LDS/FMA + HBM).
             main = torch.cuda.current_stream(dev)
             if self._aux_stream is None:
                 self._aux_stream = torch.cuda.Stream(device=dev)
             aux = self._aux_stream
-            with self._timed("circuits"):
-                q = backend.paramshift_probs(at, n, L, theta64, 0, 0, include_base=True)[0]
-                base_done = torch.cuda.Event()
-                base_done.record(main)
-                shifted = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=False)
+            start = torch.cuda.Event()
+            start.record(main)                      # theta64 is produced on the main stream
             with torch.cuda.stream(aux):
-                aux.wait_event(base_done)
+                aux.wait_event(start)
+                q = backend.paramshift_probs(at, n, L, theta64, 0, 0, include_base=True, ws_tag="base")[0]
                 with self._timed("stein"):
                     ksd2, y = self._stein_contract(q)
                 stein_done = torch.cuda.Event()
                 stein_done.record(aux)
+            with self._timed("circuits"):
+                shifted = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=False)
             main.wait_event(stein_done)
-            for tns in (ksd2, y):
+            for tns in (ksd2, y, q):
                 tns.record_stream(main)
-            q.record_stream(aux)
+            theta64.record_stream(aux)
         with self._timed("finish"):
             loss, grad_local, _ = backend.ksd_grad_finish(n, shifted, hi - lo, y, ksd2)
             grad = shard.all_gather_grad(grad_local, P, self.process_group)
