@@ -107,6 +107,68 @@ void greedy_select(const std::vector<Op>& ops, const std::vector<int>& pool, int
   }
 }
 
+// Same scan with a FIXED set of allowed target wires (a candidate local set of a pass).
+// Returns the number of locality-bound ops (U1, CNOT) it executes.
+int fixed_select(const std::vector<Op>& ops, const std::vector<int>& pool, int n, const std::vector<char>& allowed,
+                 std::vector<int>& sel, std::vector<int>& rest, std::vector<int>& targets) {
+  std::vector<char> blocked(n, 0), in_t(n, 0);
+  sel.clear(); rest.clear(); targets.clear();
+  int bound_ops = 0;
+  for (int idx : pool) {
+    const Op& o = ops[idx];
+    bool blk = blocked[o.a] || (o.b >= 0 && blocked[o.b]);
+    const int t = op_target(o);
+    if (!blk && t >= 0 && !allowed[t]) blk = true;
+    if (blk) {
+      blocked[o.a] = 1;
+      if (o.b >= 0) blocked[o.b] = 1;
+      rest.push_back(idx);
+    } else {
+      if (t >= 0) { ++bound_ops; if (!in_t[t]) { in_t[t] = 1; targets.push_back(t); } }
+      sel.push_back(idx);
+    }
+  }
+  return bound_ops;
+}
+
+// Pass selection: the program-order greedy set and every cyclic window of k consecutive wires are tried;
+// the candidate that lets this pass plus the best following pass execute the most locality-bound ops wins
+// (one step of look-ahead).  Fewer passes = fewer HBM round trips of the whole batch of states.
+void choose_pass(const std::vector<Op>& ops, const std::vector<int>& pool, int n, int k, std::vector<int>& sel,
+                 std::vector<int>& rest, std::vector<int>& targets) {
+  std::vector<std::vector<char>> cands;
+  {
+    std::vector<int> s, r, t;
+    greedy_select(ops, pool, n, k, s, r, t);
+    std::vector<char> a(n, 0);
+    for (int w : t) a[w] = 1;
+    int cnt = (int)t.size();
+    for (int w = n - 1; w >= 0 && cnt < k; --w) if (!a[w]) { a[w] = 1; ++cnt; }
+    cands.push_back(a);
+  }
+  if (k < n)
+    for (int s0 = 0; s0 < n; ++s0) {
+      std::vector<char> a(n, 0);
+      for (int j = 0; j < k; ++j) a[(s0 + j) % n] = 1;
+      cands.push_back(a);
+    }
+  long best_score = -1;
+  std::vector<int> s1, r1, t1, s2, r2, t2;
+  for (const auto& a : cands) {
+    const int here = fixed_select(ops, pool, n, a, s1, r1, t1);
+    if (s1.empty()) continue;
+    int next_best = 0;
+    if (!r1.empty() && k < n)
+      for (const auto& a2 : cands) {   // (the greedy candidate of the NEXT pool is approximated by the windows)
+        const int nb = fixed_select(ops, r1, n, a2, s2, r2, t2);
+        if (nb > next_best) next_best = nb;
+      }
+    const long score = (long)(here + next_best) * 4096 + (long)s1.size();
+    if (score > best_score) { best_score = score; sel = s1; rest = r1; targets = t1; }
+  }
+  if (best_score < 0) greedy_select(ops, pool, n, k, sel, rest, targets);
+}
+
 // Stage selection.  A stage runs its ops in five global phases -- 0: CNOTs (folded into the LDS read
 // address), 1: CZs, 2: at most one fused U per register wire, 3: CNOTs (folded into the write address),
 // 4: CZs -- so an op is accepted in the earliest phase its kind allows that is not before the phase of
@@ -255,7 +317,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     for (size_t i = 0; i < ops.size(); ++i) pool[i] = (int)i;
     std::vector<int> sel, rest, tg;
     while (!pool.empty()) {
-      greedy_select(ops, pool, n, k, sel, rest, tg);
+      choose_pass(ops, pool, n, k, sel, rest, tg);
       if (sel.empty()) { msg = "planner made no progress"; return false; }
       PassInfo pi; pi.ops = sel; pi.targets = tg;
       passes.push_back(pi);
