@@ -189,6 +189,12 @@ int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_
                            const double* y, const double* ksd2, double* loss_out,
                            double* dLdq_out, double* grad, bornvi_stream stream);
 
+/* Gradient hand-off to the optimiser (replaces the float cast of the parameter-shift VJP and
+ * torch.nn.utils.clip_grad_norm_(params, gradient_clip_norm), ksd_vi_quantum.py:153): grad32 dev [P] float32 =
+ * float32(grad64) * min(1, max_norm / (||float32(grad64)||_2 + 1e-6)); total_norm dev [1] float32 = that norm. */
+int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double max_norm,
+                          float* grad32, float* total_norm, bornvi_stream stream);
+
 /* ---- introspection (host only, no GPU needed): serialised execution plan of a circuit ------
  * (passes / stages / fused gates) as uint32 words; used by the CPU tests to check the
  * planner against the oracle.  Returns the number of words (writes min(cap, words)). */

@@ -63,7 +63,31 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_size_cache = {}
+
+
+def _cached_size(h, name, *args):
+    key = (h.device_index, name) + args
+    v = _size_cache.get(key)
+    if v is None:
+        v = _size_cache[key] = h.size(name, *args)
+    return v
+
+
+def clip_cast_grad(grad64, max_norm):
+    """float64 gradient -> (float32 gradient clipped like clip_grad_norm_, its float32 total norm [0-dim])."""
+    dev = grad64.device
+    h = _ext.handle_for(dev)
+    _chk(grad64, torch.float64, dev, "grad64")
+    g32 = torch.empty(grad64.shape, dtype=torch.float32, device=dev)
+    norm = torch.empty((), dtype=torch.float32, device=dev)
+    h.call("bornvi_clip_cast_grad", grad64.numel(), _ptr(grad64), float(max_norm), _ptr(g32), _ptr(norm),
+           _ext.stream_ptr(dev))
+    return g32, norm
+
+
 def set_option(dev, name, value):
+    _size_cache.clear()
     h = _ext.handle_for(dev)
     h.call("bornvi_set_option", name.encode(), int(value))
 
@@ -103,8 +127,8 @@ def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base
             raise BornviError("out has the wrong size")
     if B == 0:
         return out
-    need = h.size("bornvi_circuit_workspace_bytes", aid, n, layers, B)
-    ws = _ws(dev, min(need, max(WORKSPACE_CAP, h.size("bornvi_circuit_workspace_bytes", aid, n, layers, 1))), ws_tag)
+    need = _cached_size(h, "bornvi_circuit_workspace_bytes", aid, n, layers, B)
+    ws = _ws(dev, min(need, max(WORKSPACE_CAP, _cached_size(h, "bornvi_circuit_workspace_bytes", aid, n, layers, 1))), ws_tag)
     h.call("bornvi_paramshift_probs", aid, n, layers, _ptr(theta), int(p_begin), int(p_end),
            1 if include_base else 0, _ptr(out), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
     return out
@@ -193,7 +217,7 @@ def stein_quadform_rows(K_rows, r0, r1, q, n, out=None):
     nr = r1 - r0
     if out is None:
         out = torch.empty(nr + 1, dtype=torch.float64, device=dev)
-    ws = _ws(dev, h.size("bornvi_stein_quadform_workspace_bytes", n, 1), "qf")
+    ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_workspace_bytes", n, 1), "qf")
     h.call("bornvi_stein_quadform_rows", n, _ptr(K_rows), int(r0), int(r1), _ptr(q), _ptr(out),
            C.c_void_p(out.data_ptr() + 8 * nr), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
     return out
@@ -235,7 +259,7 @@ def stein_quadform_sym(K, q, n):
     _chk(q, torch.float64, dev, "q")
     y = torch.empty(1 << n, dtype=torch.float64, device=dev)
     ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
-    ws = _ws(dev, h.size("bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
+    ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
     h.call("bornvi_stein_quadform_sym", n, _ptr(K), _ptr(q), _ptr(ksd2), _ptr(y), _ptr(ws), ws.numel(),
            _ext.stream_ptr(dev))
     return ksd2, y
@@ -249,7 +273,7 @@ def stein_matvec_kron(S, q, n, length_scale=1.0):
     _chk(q, torch.float64, dev, "q")
     y = torch.empty(1 << n, dtype=torch.float64, device=dev)
     ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
-    ws = _ws(dev, h.size("bornvi_stein_matvec_kron_workspace_bytes", n), "kron")
+    ws = _ws(dev, _cached_size(h, "bornvi_stein_matvec_kron_workspace_bytes", n), "kron")
     h.call("bornvi_stein_matvec_kron", n, float(length_scale), _ptr(S), _ptr(q), _ptr(y), _ptr(ksd2), _ptr(ws),
            ws.numel(), _ext.stream_ptr(dev))
     return ksd2, y

@@ -416,6 +416,15 @@ int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_
   return BORNVI_OK;
 }
 
+int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double max_norm, float* grad32,
+                          float* total_norm, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (P < 0 || (P > 0 && (!grad64 || !grad32)) || !total_norm || !(max_norm >= 0.0)) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
   PlanOptions opt;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }

@@ -400,6 +400,31 @@ __global__ __launch_bounds__(256) void dldq_kernel(const double* __restrict__ y,
   if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) *loss_out = loss;
 }
 
+// Gradient hand-off to the optimiser in one launch: float32 cast of the float64 gradient, its 2-norm, and the
+// clip of torch.nn.utils.clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6)); ksd_vi_quantum.py:153).
+__global__ __launch_bounds__(256) void clip_cast_kernel(const double* __restrict__ g64, int P, double max_norm,
+                                                        float* __restrict__ g32, float* __restrict__ norm_out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < P; i += 256) { const float f = (float)g64[i]; acc += (double)f * (double)f; }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float total = (float)sqrt(red[0]);
+  float coef = (float)max_norm / (total + 1e-6f);
+  if (coef > 1.0f) coef = 1.0f;
+  for (int i = threadIdx.x; i < P; i += 256) g32[i] = (float)g64[i] * coef;
+  if (threadIdx.x == 0) *norm_out = total;
+}
+
+hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g32, float* norm_out, hipStream_t st) {
+  clip_cast_kernel<<<1, 256, 0, st>>>(g64, P, max_norm, g32, norm_out);
+  return hipGetLastError();
+}
+
 // ---- launchers (called from api.hip) --------------------------------------------------------------------
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
                               int shift_mode, int p_begin, int include_base, long long b_offset, int batch,

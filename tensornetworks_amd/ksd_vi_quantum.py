@@ -242,12 +242,16 @@ class KSDVariationalInference:
                        adam_betas=(0.9, 0.999)):
         """Optimiser and scheduler exactly as the reference builds them (ksd_vi_quantum.py:92-103)."""
         params = list(self.born_machine.parameters())
+        # same optimisers and hyper-parameters as the reference; when theta lives on the GPU the single-kernel
+        # ("fused") implementation of the same torch.optim class is selected: identical update rule, ~0.1 ms
+        # less host time per step
+        fused = {"fused": True} if all(p.is_cuda for p in params) else {}
         if optimizer_type == "adam":
-            optimizer_born = optim.Adam(params, lr=lr_born_machine, betas=adam_betas)
+            optimizer_born = optim.Adam(params, lr=lr_born_machine, betas=adam_betas, **fused)
         elif optimizer_type == "sgd":
-            optimizer_born = optim.SGD(params, lr=lr_born_machine, momentum=0.9)
+            optimizer_born = optim.SGD(params, lr=lr_born_machine, momentum=0.9, **fused)
         else:
-            optimizer_born = optim.Adam(params, lr=lr_born_machine)
+            optimizer_born = optim.Adam(params, lr=lr_born_machine, **fused)
         scheduler = None
         if use_lr_scheduler:
             scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer_born, T_max=num_epochs,
@@ -263,8 +267,13 @@ class KSDVariationalInference:
         if np.isnan(loss_value) or np.isinf(loss_value):
             return loss_value, None, q
         theta = self.born_machine.theta
-        theta.grad = grad64.to(device=theta.device, dtype=theta.dtype)
-        grad_norm = nn_utils.clip_grad_norm_(params, gradient_clip_norm)
+        if theta.dtype == torch.float32 and len(params) == 1:
+            # cast + clip_grad_norm_ (reference :153) in one device launch; same formula as torch's
+            g32, grad_norm = backend.clip_cast_grad(grad64, gradient_clip_norm)
+            theta.grad = g32.to(theta.device)
+        else:
+            theta.grad = grad64.to(device=theta.device, dtype=theta.dtype)
+            grad_norm = nn_utils.clip_grad_norm_(params, gradient_clip_norm)
         optimizer_born.step()
         if scheduler is not None:
             scheduler.step()
