@@ -146,11 +146,14 @@ constexpr int MAX_TILE_ITERS = 16;  // tile elements per thread in the HBM <-> L
 // grid = (2^(n-k) tiles, circuits); block = plan threads; dynamic LDS = 2^k * 16 bytes.
 // FULL = every thread moves exactly MAX_TILE_ITERS tile elements (k >= 10: threads = 2^(k-4)), which lets
 // all loads of the tile stay in registers; the generic instantiation handles small tiles.
-template <bool FULL>
+template <bool FULL, bool DEBUG>
 __global__ __launch_bounds__(512) void circuit_pass_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const double2* __restrict__ in,
     double2* __restrict__ out, double* __restrict__ probs, const double* __restrict__ gates,
-    long long gate_stride, long long state_stride, int dbg) {
+    long long gate_stride, long long state_stride, int dbg_arg) {
+  // timing-only ablation flags exist only in the DEBUG instantiation: in the production kernel every
+  // `dbg` test folds away (as run-time tests they cost a scalar branch per LDS access)
+  const int dbg = DEBUG ? dbg_arg : 0;
   extern __shared__ double2 tile[];
   const uint32_t* __restrict__ P = plan + pass_off;
   uint32_t H[PW_HEADER_WORDS];   // whole pass header with two wide scalar loads
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
   // ---- this circuit's fused matrices for every stage of the pass -> LDS (one 16-byte piece per thread;
   // they were written by build_gates_kernel on other CUs, i.e. they come from far memory: fetch them once,
   // under the tile loads, instead of stalling every stage on them)
-  for (uint32_t piece = t; piece < (uint32_t)nstages * 16u; piece += T) {
+  for (uint32_t piece = t; piece < (uint32_t)nstages * 16u && !(dbg & 32); piece += T) {
     const uint32_t sm = piece >> 2;                               // (stage, register bit)
     const uint32_t w = P[PW_MATS + (sm >> 1)];
     const uint32_t f = (sm & 1u) ? (w >> 16) : (w & 0xffffu);
@@ -217,36 +220,52 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
 
   // ---- stages: 2^r amplitudes per thread in registers, one LDS round trip each -----------------------
   // Fixed form (plan.hpp): read with the phase-0 CNOT permutation folded into the address, optional sign,
-  // one fused U per register wire (all four matrices fetched up front by scalar loads), optional sign on
-  // the permuted index, write with the phase-3 CNOT permutation folded into the address.
+  // one fused U per register wire (matrices in LDS), optional sign on the permuted index, write with the
+  // phase-3 CNOT permutation folded into the address.  All per-stage index arithmetic was done by the
+  // planner: a thread fetches its (swizzled base | base << 16) word from the stage's table -- one stage ahead,
+  // so the L2 latency hides under the current stage -- and the 32 slot offsets come as whole scalar words.
+  // FULL implies r == 4 (k >= 10): no per-slot guards.
   const uint32_t* __restrict__ S = P + PW_STAGES;
-  for (int s = 0; s < nstages; ++s) {
-    uint32_t G[STAGE_HDR_WORDS];     // stage header with two wide scalar loads
+  uint32_t base_word = 0;
+  {
+    const uint32_t hdr0 = nstages > 0 ? S[0] : 0u;
+    const uint32_t npay0 = (((hdr0 >> 8) & STAGE_SIGN_PRE) ? SIGNQ_WORDS : 0) + (((hdr0 >> 8) & STAGE_SIGN_POST) ? SIGNQ_WORDS : 0);
+    if (nstages > 0 && t < (1u << (k - (int)(hdr0 & 0xffu)))) base_word = S[STAGE_HDR_WORDS + npay0 + t];
+  }
+  for (int s = 0; s < nstages && !(dbg & 64); ++s) {
+    uint32_t G[STAGE_HDR_WORDS];     // stage header with three wide scalar loads
 #pragma unroll
     for (int i = 0; i < STAGE_HDR_WORDS; ++i) G[i] = S[i];
     const uint32_t hdr = G[0];
-    const int r = (int)(hdr & 0xffu);
+    const int r = FULL ? 4 : (int)(hdr & 0xffu);
     const uint32_t sflags = (hdr >> 8) & 0xffu;
     const uint32_t nwords = hdr >> 16;
+    const uint32_t my_word = base_word;
+    if (s + 1 < nstages) {           // prefetch the next stage's table entry
+      const uint32_t* __restrict__ Sn = S + nwords;
+      const uint32_t hdrn = Sn[0];
+      const uint32_t npayn = (((hdrn >> 8) & STAGE_SIGN_PRE) ? SIGNQ_WORDS : 0) + (((hdrn >> 8) & STAGE_SIGN_POST) ? SIGNQ_WORDS : 0);
+      if (t < (1u << (k - (int)(hdrn & 0xffu)))) base_word = Sn[STAGE_HDR_WORDS + npayn + t];
+    }
     if (t < (1u << (k - r))) {
       const uint32_t rho = G[1];
       const uint32_t fi[4] = {G[6] & 0xffffu, G[6] >> 16, G[7] & 0xffffu, G[7] >> 16};
       const double2* __restrict__ Us = mats + s * 16;
-      const uint32_t tpos[4] = {G[2], G[3], G[4], G[5]};
-      const uint32_t base = deposit16(t, 0, k - r, tpos);
-      const uint32_t pb = lds_swizzle(base);
-      const uint32_t e = base | (g << k);  // extended index: LDS bits then workgroup bits
+      const uint32_t pb = my_word & 0xffffu;
+      const uint32_t e = (my_word >> 16) | (g << k);  // extended index: LDS bits then workgroup bits
       uint32_t lflip = 0, sflip = 0, e2 = e;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t rp = (rho >> (8 * i)) & 0xffu;
-        const uint32_t sri = (i < r) ? lds_swizzle(1u << rp) : 0u;
         const uint32_t bpre = G[8 + i], bpost = G[12 + i];
-        if (bpre) lflip ^= (__popc(e & bpre) & 1) ? sri : 0u;
-        if (bpost) {
-          const uint32_t bit = (uint32_t)__popc(e & bpost) & 1u;
-          sflip ^= bit ? sri : 0u;
-          e2 |= bit << rp;
+        if (bpre | bpost) {
+          const uint32_t rp = (rho >> (8 * i)) & 0xffu;
+          const uint32_t sri = lds_swizzle(1u << rp);
+          if (bpre) lflip ^= (__popc(e & bpre) & 1) ? sri : 0u;
+          if (bpost) {
+            const uint32_t bit = (uint32_t)__popc(e & bpost) & 1u;
+            sflip ^= bit ? sri : 0u;
+            e2 |= bit << rp;
+          }
         }
       }
       const int nreg = 1 << r;
@@ -254,24 +273,21 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
       double ar[16], ai[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const uint32_t off = (G[16 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
-        if (j < nreg && !(dbg & 2)) { const double2 v = tile[rbase ^ off]; ar[j] = v.x; ai[j] = v.y; }
+        if ((FULL || j < nreg) && !(dbg & 2)) { const double2 x = tile[rbase ^ G[16 + j]]; ar[j] = x.x; ai[j] = x.y; }
         else { ar[j] = (double)(rbase + j); ai[j] = 0.0; }
       }
       const uint32_t* __restrict__ Q = S + STAGE_HDR_WORDS;
-      if (sflags & STAGE_SIGN_PRE) { apply_sign(Q, e, n, ar, ai); Q += SIGNQ_WORDS; }
+      if ((sflags & STAGE_SIGN_PRE) && !(dbg & 128)) { apply_sign(Q, e, n, ar, ai); Q += SIGNQ_WORDS; }
       if (!(dbg & 1)) {
         if (fi[0] != 0xffffu) op_u1<0>(ar, ai, Us);
         if (fi[1] != 0xffffu) op_u1<1>(ar, ai, Us + 4);
         if (fi[2] != 0xffffu) op_u1<2>(ar, ai, Us + 8);
         if (fi[3] != 0xffffu) op_u1<3>(ar, ai, Us + 12);
       }
-      if (sflags & STAGE_SIGN_POST) apply_sign(Q, e2, n, ar, ai);
+      if ((sflags & STAGE_SIGN_POST) && !(dbg & 128)) apply_sign(Q, e2, n, ar, ai);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const uint32_t off = (G[24 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
-        if (j < nreg && !(dbg & 2)) tile[wbase ^ off] = make_double2(ar[j], ai[j]);
-      }
+      for (int j = 0; j < 16; ++j)
+        if ((FULL || j < nreg) && !(dbg & 2)) tile[wbase ^ G[32 + j]] = make_double2(ar[j], ai[j]);
       if (dbg & 2) {   // timing-only build of the stage without LDS traffic: keep the values alive
         double acc = 0.0;
 #pragma unroll
@@ -438,11 +454,15 @@ hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* th
 }
 
 hipError_t prepare_circuit_kernel(size_t lds_bytes) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_kernel<false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  const void* fns[4] = {reinterpret_cast<const void*>(circuit_pass_kernel<true, false>),
+                        reinterpret_cast<const void*>(circuit_pass_kernel<false, false>),
+                        reinterpret_cast<const void*>(circuit_pass_kernel<true, true>),
+                        reinterpret_cast<const void*>(circuit_pass_kernel<false, true>)};
+  for (const void* f : fns) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, int batch,
@@ -453,12 +473,14 @@ hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, i
   while ((1 << tau) < threads) ++tau;
   const bool full = (k - tau) == 4;   // 16 tile elements per thread
   const size_t lds = (size_t(1) << k) * 16 + (size_t)MAX_STAGES * STAGE_MATS_BYTES;
-  if (full)
-    circuit_pass_kernel<true><<<grid, dim3(threads), lds, st>>>(
-        plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg);
-  else
-    circuit_pass_kernel<false><<<grid, dim3(threads), lds, st>>>(
-        plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg);
+#define BORNVI_LAUNCH_PASS(F, D)                                                     \
+  circuit_pass_kernel<F, D><<<grid, dim3(threads), lds, st>>>(                       \
+      plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg)
+  if (full && !dbg) BORNVI_LAUNCH_PASS(true, false);
+  else if (full) BORNVI_LAUNCH_PASS(true, true);
+  else if (!dbg) BORNVI_LAUNCH_PASS(false, false);
+  else BORNVI_LAUNCH_PASS(false, true);
+#undef BORNVI_LAUNCH_PASS
   return hipGetLastError();
 }
 

@@ -521,16 +521,19 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       W[base + PW_MATS + 2 * nstages + 1] = W[sbase + 7];
       for (int t = 0; t < 4; ++t) { W[sbase + 8 + t] = t < r ? pre[t].bext : 0u; W[sbase + 12 + t] = t < r ? post[t].bext : 0u; }
       for (int j = 0; j < 16; ++j) {
-        const uint32_t lo_ = (j < (1 << r)) ? lds_swizzle(slot_offset(pre, j)) : 0u;
-        const uint32_t so_ = (j < (1 << r)) ? lds_swizzle(slot_offset(post, j)) : 0u;
-        W[sbase + 16 + j / 2] |= lo_ << (16 * (j & 1));
-        W[sbase + 24 + j / 2] |= so_ << (16 * (j & 1));
+        W[sbase + 16 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(pre, j)) : 0u;
+        W[sbase + 32 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(post, j)) : 0u;
       }
       uint32_t flags = 0;
       Expr ident[4];
       for (int t = 0; t < 4; ++t) ident[t] = Expr{1u << t, 0u};
       if (!sel.pre_cz.empty()) { flags |= STAGE_SIGN_PRE; emit_signq(sel.pre_cz, ident); }
       if (!sel.post_cz.empty()) { flags |= STAGE_SIGN_POST; emit_signq(sel.post_cz, post); }
+      for (uint32_t tt = 0; tt < (1u << (k - r)); ++tt) {   // per-thread base table
+        uint32_t bse = 0;
+        for (size_t j = 0; j < freepos.size(); ++j) bse |= ((tt >> j) & 1u) << freepos[j];
+        W.push_back(lds_swizzle(bse) | (bse << 16));
+      }
       const uint32_t nwords = (uint32_t)W.size() - sbase;
       if (nwords >= (1u << 16)) { msg = "stage too large"; return false; }
       W[sbase] = (uint32_t)r | (flags << 8) | (nwords << 16);

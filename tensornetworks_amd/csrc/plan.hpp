@@ -68,17 +68,19 @@ constexpr int STAGE_MATS_BYTES = 4 * 64; // LDS bytes of one stage's four 2x2 co
 constexpr uint32_t PASS_INIT = 1u;   // tile starts as |0...0> (no HBM read)
 constexpr uint32_t PASS_FINAL = 2u;  // epilogue writes |psi|^2 in canonical order
 constexpr uint32_t PASS_FINAL_STATE = 4u;  // epilogue writes the state itself in canonical order
-// stage (fixed form, see plan.cpp): STAGE_HDR_WORDS words, then optional sign payloads
+// stage (fixed form, see plan.cpp): STAGE_HDR_WORDS words, optional sign payloads, then the base table
 //   [0]      r | flags << 8 | nwords << 16
 //   [1]      rho: 4 bytes, LDS bit position of register bit t
-//   [2..5]   tpos: 16 bytes, LDS bit position receiving thread-id bit j
+//   [2..5]   tpos: 16 bytes, LDS bit position receiving thread-id bit j   (emulator / generic kernel)
 //   [6..7]   fused gate index of register bit t (16 bits each, 0xffff = no gate)
 //   [8..11]  Bpre[t]:  parity(e & Bpre[t]) flips register bit t of the LDS READ index
 //   [12..15] Bpost[t]: same for the LDS WRITE index        (e = extended index: LDS bits, then workgroup bits)
-//   [16..23] load_off[16]:  16 bits each, swizzled LDS offset register slot j is read from
-//   [24..31] store_off[16]: 16 bits each, swizzled LDS offset register slot j is written to
-//   then SIGNQ_WORDS words if STAGE_SIGN_PRE, then SIGNQ_WORDS words if STAGE_SIGN_POST
-constexpr int STAGE_HDR_WORDS = 32;
+//   [16..31] load_off[16]:  swizzled LDS offset register slot j is read from
+//   [32..47] store_off[16]: swizzled LDS offset register slot j is written to
+//   then SIGNQ_WORDS words if STAGE_SIGN_PRE, then SIGNQ_WORDS words if STAGE_SIGN_POST,
+//   then 2^(k-r) words: thread t's  lds_swizzle(base_t) | base_t << 16  (base_t = t's bits deposited at the
+//   non-register LDS positions) -- index arithmetic done once by the planner instead of per stage per thread
+constexpr int STAGE_HDR_WORDS = 48;
 constexpr uint32_t STAGE_SIGN_PRE = 1u;
 constexpr uint32_t STAGE_SIGN_POST = 2u;
 // sign payload (product of CZ gates = (-1)^{q(x)}, q a quadratic form over the extended index bits):

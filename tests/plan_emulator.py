@@ -16,7 +16,7 @@ PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
 PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_LDS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_STAGES = 8, 12, 16, 20, 24, 32, 64, 160
 PW_MATS = 96
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
-STAGE_HDR_WORDS = 32
+STAGE_HDR_WORDS = 48
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
 SIGNQ_WORDS = 49
 KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
@@ -128,8 +128,8 @@ def run_plan(W, mats, state_in=None):
                     e2 |= bit << rpos[i]
                 for i in range(r, 4):
                     assert int(S[8 + i]) == 0 and int(S[12 + i]) == 0
-                loff = [(int(S[16 + (j >> 1)]) >> (16 * (j & 1))) & 0xFFFF for j in range(16)]
-                soff = [(int(S[24 + (j >> 1)]) >> (16 * (j & 1))) & 0xFFFF for j in range(16)]
+                loff = [int(S[16 + j]) for j in range(16)]
+                soff = [int(S[32 + j]) for j in range(16)]
                 rd = [swz_inv(pb ^ lflip ^ loff[j]) for j in range(nreg)]
                 wr = [swz_inv(pb ^ sflip ^ soff[j]) for j in range(nreg)]
                 # a thread reads and writes exactly its own 2^r-element group (no cross-thread hazard),
@@ -157,6 +157,10 @@ def run_plan(W, mats, state_in=None):
                 if sflags & STAGE_SIGN_POST:
                     apply_sign(S[q_off: q_off + SIGNQ_WORDS], e2, n, amp, nreg)
                     q_off += SIGNQ_WORDS
+                # per-thread base table emitted by the planner == the deposit the header describes
+                tab = S[q_off: q_off + nthr].astype(np.int64)
+                assert np.array_equal(tab & 0xFFFF, pb) and np.array_equal(tab >> 16, base)
+                q_off += nthr
                 assert q_off == nwords, (q_off, nwords)
                 for j in range(nreg):
                     tile[wr[j]] = amp[j]
