@@ -125,12 +125,13 @@ def get_sprinkler_network(random_cpts=False):
     return bn
 
 
-def synthetic_network(n, seed=0):
+def synthetic_network(n, seed=0, p_low=0.01, p_high=0.99):
     """n latent nodes Z0..Z{n-1} plus one observed leaf X.
 
     Z_k has parents [Z_{k-1}] (+ [Z_{k-2}] when k is even and k >= 2); X has parents
-    [Z_{n-2}, Z_{n-1}] (just [Z_0] when n == 1).  Every P(node=1 | parents) ~ U(0.01, 0.99)
-    from ``numpy.random.default_rng(seed)``, drawn node by node, parent configurations in
+    [Z_{n-2}, Z_{n-1}] (just [Z_0] when n == 1).  Every P(node=1 | parents) ~ U(p_low, p_high)
+    (default U(0.01, 0.99), the reference's ``random_p``, bayesian_network.py:323) from
+    ``numpy.random.default_rng(seed)``, drawn node by node, parent configurations in
     lexicographic order.  Returns (bn, latent_names, observed_names, x_observation_dict).
     """
     rng = np.random.default_rng(seed)
@@ -139,7 +140,7 @@ def synthetic_network(n, seed=0):
     def table(num_parents):
         tab = {}
         for cfg in generate_all_binary_outcomes(num_parents):
-            p1 = float(rng.uniform(0.01, 0.99))
+            p1 = float(rng.uniform(p_low, p_high))
             tab[cfg] = {0: 1.0 - p1, 1: p1}
         return tab
 

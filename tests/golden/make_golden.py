@@ -152,10 +152,37 @@ def classical_trace():
     print("classical_trace: losses", losses, "forwards recorded", len(qs))
 
 
+def adversarial_tables():
+    """Prior p(z) and log p(x|z) exactly as the reference's adversarial trainer computes them
+    (adversarial_vi.py:37-47, :60-102), for every latent state, plus the default classifier's layer shapes."""
+    import adversarial_vi as ref_adv                 # reference
+    out = {}
+    cases = {"sprinkler": (ref_bn.get_sprinkler_network(False), ['C', 'S', 'R'], ['W'])}
+    ours5, lat5, obs5, _ = synthetic_network(5, 0)
+    cases["synthetic_n5_s0"] = (to_ref_bn(ours5), lat5, obs5)
+    for tag, (bn, lat, obs) in cases.items():
+        torch.manual_seed(0)
+        adv = ref_adv.AdversarialVariationalInference(bn, lat, obs, born_machine_config={'use_logits': True, 'conditioning_dim': 0},
+                                                      classifier_config={}, device='cpu')
+        outs = ref_utils.generate_all_binary_outcomes(len(lat))
+        out[f"{tag}_prior"] = np.array([adv.prior_z_dist_dict[z] for z in outs])
+        out[f"{tag}_prior_f32"] = adv.prior_z_probs.numpy().copy()
+        Z = torch.tensor(outs, dtype=torch.float32)
+        for xv in (0, 1):
+            out[f"{tag}_logp_x{xv}"] = adv._get_log_p_x_given_z(torch.tensor([float(xv)]), Z).numpy().copy()
+        out[f"{tag}_clf_shapes"] = np.array([list(p.shape) + [0] * (2 - p.dim()) for p in adv.classifier.parameters()])
+    np.savez(os.path.join(HERE, "adversarial_tables.npz"), **out)
+    print("adversarial_tables:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-n8", action="store_true")
+    ap.add_argument("--only-adversarial", action="store_true")
     args = ap.parse_args()
+    if args.only_adversarial:
+        adversarial_tables()
+        sys.exit(0)
     two_node_kat()
     sprinkler_case("w1", ref_bn.get_sprinkler_network(False), {'W': 1})
     sprinkler_case("w0", ref_bn.get_sprinkler_network(False), {'W': 0})
@@ -166,6 +193,7 @@ if __name__ == "__main__":
         synthetic_case(n, 0)
     synthetic_case(5, 1)
     classical_trace()
+    adversarial_tables()
     if not args.skip_n8:
         # 32 of the 256 rows of K (each row = 256 reference k_p calls), full S
         synthetic_case(8, 0, rows=list(range(0, 256, 8)))

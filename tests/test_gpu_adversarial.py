@@ -1,0 +1,79 @@
+"""Adversarial-VI path (SURVEY.md section 8(f) row 1 / BASELINE config 5) on the MI355X backend: the tables the
+reference computes per sample (adversarial_vi.py:37-47, :60-102) against golden vectors captured from the
+reference, the trainer's API / history, and one run at config-5 shape (n = 12 qubits, batch 65,536)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tensornetworks_amd.bayesian_network import get_sprinkler_network, synthetic_network
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make(bn, lat, obs, device="cuda:0", layers=2, seed=0, **clf):
+    from tensornetworks_amd.adversarial_vi import AdversarialVariationalInference
+    torch.manual_seed(seed)
+    return AdversarialVariationalInference(bn, lat, obs, born_machine_config={'ansatz_layers': layers, 'conditioning_dim': 0},
+                                           classifier_config=clf, device=device)
+
+
+@pytest.mark.parametrize("tag", ["sprinkler", "synthetic_n5_s0"])
+def test_prior_and_log_likelihood_tables_match_reference(tag):
+    g = golden("adversarial_tables.npz")
+    if tag == "sprinkler":
+        bn, lat, obs = get_sprinkler_network(False), ['C', 'S', 'R'], ['W']
+    else:
+        bn, lat, obs, _ = synthetic_network(5, 0)
+    adv = make(bn, lat, obs)
+    n = len(lat)
+    np.testing.assert_allclose(np.array([adv.prior_z_dist_dict[z] for z in adv.prior_z_outcomes]), g[f"{tag}_prior"], rtol=1e-14)
+    np.testing.assert_allclose(adv.prior_z_probs.cpu().numpy(), g[f"{tag}_prior_f32"], rtol=2e-7)
+    Z = torch.tensor(adv.prior_z_outcomes, dtype=torch.float32, device="cuda:0")
+    for xv in (0, 1):
+        lp = adv._get_log_p_x_given_z(torch.tensor([float(xv)]), Z)
+        assert lp.dtype == torch.float32 and lp.shape == (2 ** n,)
+        np.testing.assert_allclose(lp.cpu().numpy(), g[f"{tag}_logp_x{xv}"], rtol=3e-6, atol=3e-7)
+    shapes = [list(p.shape) + [0] * (2 - p.dim()) for p in adv.classifier.parameters()]
+    assert shapes == g[f"{tag}_clf_shapes"].tolist()          # same default architecture (classifier_pytorch.py:27-41)
+    s = adv._sample_from_prior_z(4000)
+    assert s.shape == (4000, n) and s.dtype == torch.float32
+    emp = torch.bincount(adv._index(s), minlength=2 ** n).double().cpu().numpy() / 4000
+    assert np.abs(emp - g[f"{tag}_prior"]).max() < 0.05
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda:0"])
+def test_training_moves_towards_the_posterior(device):
+    bn = get_sprinkler_network(False)
+    lat, obs, x = ['C', 'S', 'R'], ['W'], {'W': 1}
+    adv = make(bn, lat, obs, device=device, layers=3, seed=1)
+    post, _ = bn.get_true_posterior(lat, x)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        hist = adv.train(x, num_epochs=60, batch_size=512, lr_born_machine=0.03, lr_classifier=0.01,
+                         k_classifier_steps=3, k_born_steps=1, verbose=True, true_posterior_for_tvd=post)
+    assert set(hist) == {'loss_classifier', 'loss_born_machine', 'tvd', 'grad_norm_born', 'grad_norm_classifier'}
+    assert all(len(v) == 60 for v in hist.values()) and np.all(np.isfinite(hist['loss_born_machine']))
+    assert "Loss D:" in buf.getvalue() and "Loss G:" in buf.getvalue() and "LR_G:" in buf.getvalue()
+    assert min(hist['tvd']) < 0.75 * hist['tvd'][0]           # the variational family moves towards p(z|x)
+    with pytest.raises(ValueError, match="Keys in x_observation_dict"):
+        adv.train({'Q': 1}, 1, 8, 0.01, 0.01, verbose=False)
+
+
+def test_config5_shape_runs():
+    """n = 12 qubits, REINFORCE batch 65,536, classifier forward/backward -- two epochs."""
+    n = 12
+    # milder CPTs than the KSD benchmarks: with U(0.01, 0.99) tables some of the 4096 states have
+    # p(z) < 1e-9, for which the reference's rule (adversarial_vi.py:91-96) makes the reward infinite
+    bn, lat, obs, x = synthetic_network(n, 0, p_low=0.25, p_high=0.75)
+    adv = make(bn, lat, obs, layers=4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        hist = adv.train(x, num_epochs=2, batch_size=65536, lr_born_machine=0.003, lr_classifier=0.03,
+                         k_classifier_steps=5, k_born_steps=1, verbose=False, adam_betas=(0.5, 0.999))
+    assert np.all(np.isfinite(hist['loss_classifier'])) and np.all(np.isfinite(hist['loss_born_machine']))
+    assert hist['grad_norm_born'][-1] > 0
+    g = adv.born_machine.theta.grad
+    assert g is not None and g.shape == (144,) and torch.isfinite(g).all()
