@@ -179,3 +179,37 @@ def test_full_size_properties(be, dev):
         qq = be.circuit_probs(ansatz, n, L, torch.stack([tp, tm]))
         fd = ((qq[0] - qq[1]) @ w).item() / (2 * h)
         assert abs(gp - fd) < 1e-7 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+def test_full_depth_n16_against_c_port(be, dev, ansatz):
+    """All three ansaetze at n = 16, L = 6 (multi-tile plans, default tile size) against the oracle's C port."""
+    from oracle import cpu_port as cp
+    if not cp.available():
+        pytest.skip("oracle/_build/libcpu_port.so not built")
+    n, L = 16, 6
+    rng = np.random.default_rng(42)
+    th = rng.uniform(-np.pi, np.pi, (3, oc.num_params(ansatz, n, L)))
+    q = gpu_probs(be, dev, ansatz, n, L, th)
+    np.testing.assert_allclose(q, cp.circuit_probs(ansatz, n, L, th), rtol=1e-9, atol=1e-16)
+
+
+def test_n20_circuit_and_kron_matvec(be, dev):
+    """BASELINE config 4 size (n = 20): circuits (L = 1, 256 tiles per state) and the matrix-free Stein
+    mat-vec against the CPU oracle."""
+    from oracle import stein as os_
+    from tensornetworks_amd.bayesian_network import synthetic_network, pack_network
+    n, L = 20, 1
+    rng = np.random.default_rng(20)
+    th = rng.uniform(-np.pi, np.pi, (2, oc.num_params("hardware_efficient", n, L)))
+    q = gpu_probs(be, dev, "hardware_efficient", n, L, th)
+    for b in range(2):
+        np.testing.assert_allclose(q[b], oc.probs("hardware_efficient", n, L, th[b]), rtol=1e-9, atol=1e-17)
+    bn, lat, obs, x = synthetic_network(n, 0)
+    S, pxz = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    qq = torch.as_tensor(q[0], device=dev)
+    k2, y = be.stein_matvec_kron(S, qq, n, 1.0)
+    y_o = os_.stein_matvec_kron(S.cpu().numpy(), q[0], n)
+    scale = np.abs(y_o).max()
+    np.testing.assert_allclose(y.cpu().numpy(), y_o, rtol=0, atol=1e-10 * scale)
+    assert abs(k2.item() - float(q[0] @ y_o)) <= 1e-9 * abs(float(q[0] @ y_o))

@@ -135,3 +135,42 @@ def test_shard_ranges_cover_all_parameters():
                 got += list(range(lo, hi))
             assert got == list(range(P))
     assert shard_range(288, 3, 8) == (108, 144) and shard_range(480, 7, 8) == (420, 480)
+
+
+def test_planner_property_random_configurations():
+    """Property test: for random (ansatz, n, layers, tile size) the emitted plan reproduces the oracle."""
+    from hypothesis import given, settings, strategies as st
+    from tensornetworks_amd import _ext
+
+    @settings(max_examples=25, deadline=None, derandomize=True)
+    @given(st.sampled_from(oc.ANSATZ_TYPES), st.integers(1, 9), st.integers(0, 3), st.integers(4, 13), st.integers(0, 10 ** 6))
+    def check(ansatz, n, L, kb, seed):
+        W = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, L, kb)
+        th = np.random.default_rng(seed).uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
+        q = pe.run_plan(W, pe.fused_matrices(W, th))
+        np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
+        assert abs(q.sum() - 1) < 1e-13
+    check()
+
+
+def test_c_port_matches_numpy_oracle():
+    from oracle import cpu_port as cp
+    if not cp.available():
+        pytest.skip("oracle/_build/libcpu_port.so not built (run __graft_entry__.build())")
+    rng = np.random.default_rng(1)
+    for ansatz in oc.ANSATZ_TYPES:
+        th = rng.uniform(-3, 3, (2, oc.num_params(ansatz, 7, 2)))
+        q = cp.circuit_probs(ansatz, 7, 2, th)
+        for b in range(2):
+            np.testing.assert_allclose(q[b], oc.probs(ansatz, 7, 2, th[b]), rtol=0, atol=1e-15)
+    g = golden("synthetic_n6_s0.npz")
+    K = cp.gram_rows(g["S"], 6, 1.0, 0, 64)
+    np.testing.assert_allclose(K, g["K"], rtol=0, atol=3e-15 * np.abs(g["K"]).max())
+    q = rng.random(64); q /= q.sum()
+    y, part = cp.gemv_rows(K[8:24], 6, 8, 24, q)
+    np.testing.assert_allclose(y, K[8:24] @ q, rtol=1e-14)
+    assert abs(part - q[8:24] @ (K[8:24] @ q)) < 1e-12 * abs(part)
+    pr, used = cp.paramshift_probs("basic", 5, 2, th[0][:20], 2, 4, True)
+    tp = th[0][:20].copy(); tp[3] -= np.pi / 2
+    np.testing.assert_allclose(pr[4], oc.probs("basic", 5, 2, tp), atol=1e-15)
+    assert pr.shape == (5, 32) and used >= 1
