@@ -222,7 +222,8 @@ class KSDVariationalInference:
             start.record(main)                      # theta64 is produced on the main stream
             with torch.cuda.stream(aux):
                 aux.wait_event(start)
-                q = backend.paramshift_probs(at, n, L, theta64, 0, 0, include_base=True, ws_tag="base")[0]
+                with self._timed("base_circuit"):
+                    q = backend.paramshift_probs(at, n, L, theta64, 0, 0, include_base=True, ws_tag="base")[0]
                 with self._timed("stein"):
                     ksd2, y = self._stein_contract(q)
                 stein_done = torch.cuda.Event()

@@ -1,0 +1,31 @@
+"""Per-rank cost of the W-way sharded step on ONE GPU (no communication): rank 0's share of the shifted circuits and
+of the Gram rows, with the two all-gathers replaced by local zero-padding.  Timing aid for the strong-scaling path."""
+import sys, time, io, contextlib
+sys.path.insert(0, '/root/repo')
+import torch
+from tensornetworks_amd import paramshift_shard as shard
+from tensornetworks_amd.bayesian_network import synthetic_network
+from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n, L = 16, 6
+shard.world = lambda group=None: (0, W)
+def fake_flat(out, msg, group=None):
+    out.zero_(); out.view(W, -1)[0].copy_(msg); return out
+shard.all_gather_flat = fake_flat
+bn, lat, obs, x = synthetic_network(n, 0)
+torch.manual_seed(0)
+vi = KSDVariationalInference(bn, lat, obs, n, L, pytorch_device='cuda:0', gram_mode='dense')
+vi._prepare_stein(x)
+params, opt, sched = vi.make_optimizer(0.005, 100)
+for _ in range(3):
+    vi.training_step(params, opt, sched, 10.0)
+torch.cuda.synchronize(); vi.timers = {}
+t0 = time.perf_counter()
+K = 20
+for _ in range(K):
+    vi.training_step(params, opt, sched, 10.0)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / K * 1e3
+ph = {k: round(sum(a.elapsed_time(b) for a, b in v) / len(v), 3) for k, v in vi.timers.items()}
+print(f"emulated rank 0 of {W}: {ms:.3f} ms/step  phases {ph}  K rows {vi._K.shape[0]}")
