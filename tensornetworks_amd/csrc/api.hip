@@ -88,7 +88,7 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
   for (int i = 0; i < p.n_passes; ++i) {
     const bool last = (i == p.n_passes - 1);
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
-    HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, bc, in, out, final_probs, gates, gate_stride, h->debug_flags, st));
+    HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, p.lds_bytes(), bc, in, out, final_probs, gates, gate_stride, h->debug_flags, st));
     in = out;
   }
   return BORNVI_OK;

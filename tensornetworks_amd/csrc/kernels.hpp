@@ -12,7 +12,7 @@ hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* th
                               int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
                               double* gates, hipStream_t st);
 hipError_t prepare_circuit_kernel(size_t lds_bytes);
-hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, int batch,
+hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,
                                const void* in, void* out, double* probs, const double* gates,
                                long long gate_stride, int dbg, hipStream_t st);
 hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st);

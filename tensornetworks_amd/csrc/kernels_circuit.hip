@@ -465,14 +465,13 @@ hipError_t prepare_circuit_kernel(size_t lds_bytes) {
   return hipSuccess;
 }
 
-hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, int batch,
+hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,
                                const void* in, void* out, double* probs, const double* gates,
                                long long gate_stride, int dbg, hipStream_t st) {
   dim3 grid(1u << (n - k), (unsigned)batch);
   int tau = 0;
   while ((1 << tau) < threads) ++tau;
   const bool full = (k - tau) == 4;   // 16 tile elements per thread
-  const size_t lds = (size_t(1) << k) * 16 + (size_t)MAX_STAGES * STAGE_MATS_BYTES;
 #define BORNVI_LAUNCH_PASS(F, D)                                                     \
   circuit_pass_kernel<F, D><<<grid, dim3(threads), lds, st>>>(                       \
       plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg)

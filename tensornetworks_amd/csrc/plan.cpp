@@ -392,6 +392,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
 
   // ---- serialise ------------------------------------------------------------------------------
   std::vector<uint32_t>& W = plan.words;
+  plan.max_stages = 0;
   W.assign(PH_SIZE, 0);
   W[PH_MAGIC] = PLAN_MAGIC; W[PH_N] = n; W[PH_K] = k; W[PH_NPASSES] = np;
   W[PH_NFUSED] = (uint32_t)fused.size(); W[PH_NPARAMS] = (uint32_t)spec.n_params;
@@ -541,6 +542,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       pool = rest;
     }
     W[base + PW_NSTAGES] = nstages;
+    if ((int)nstages > plan.max_stages) plan.max_stages = (int)nstages;
   }
   W[PH_TOTAL] = (uint32_t)W.size();
   plan.n = n; plan.k = k; plan.r = r; plan.n_passes = np; plan.n_fused = (int)fused.size();

@@ -108,9 +108,11 @@ struct PlanOptions {
 
 struct Plan {
   int n = 0, k = 0, r = 0, n_passes = 0, n_fused = 0, n_params = 0, threads = 0, n_gates = 0;
+  int max_stages = 0;   // most stages in any one pass (sizes the LDS matrix area)
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;  // word offset of each pass descriptor
-  size_t lds_bytes() const { return (size_t(1) << k) * 16 + (size_t)MAX_STAGES * STAGE_MATS_BYTES; }
+  // tile + the matrices of the longest pass, rounded up to 512 bytes
+  size_t lds_bytes() const { return (size_t(1) << k) * 16 + (((size_t)(max_stages > 0 ? max_stages : 1) * STAGE_MATS_BYTES + 511) / 512) * 512; }
 };
 
 // Returns false (with msg) on unsupported sizes.
