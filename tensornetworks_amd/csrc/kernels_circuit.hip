@@ -140,6 +140,28 @@ __device__ __forceinline__ uint32_t deposit16(uint32_t v, int from, int to, cons
   return o;
 }
 
+// entry `idx` (compile-time) of a table of sixteen 16-bit values held in eight registers
+__device__ __forceinline__ uint32_t half16(const uint32_t (&w)[8], int idx) {
+  return (w[idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+}
+
+// xor over bits j in [0, nbits) of v of table[j]  (GF(2)-linear map of an index into a swizzled LDS slot)
+__device__ __forceinline__ uint32_t xor_map16(uint32_t v, int nbits, const uint32_t (&table)[8]) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nbits) o ^= (0u - ((v >> j) & 1u)) & half16(table, j);
+  return o;
+}
+
+// table entry at a run-time (wave-uniform) index
+__device__ __forceinline__ uint32_t half16_dyn(const uint32_t (&w)[8], int idx) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o = (j == idx) ? half16(w, j) : o;
+  return o;
+}
+
 constexpr int MAX_TILE_ITERS = 16;  // tile elements per thread in the HBM <-> LDS phases (2^13 / 512)
 
 // One pass of the circuit program over one 2^k-amplitude tile per workgroup.
@@ -165,7 +187,12 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
   const int lo_in = (int)H[PW_LO_IN], lo_out = (int)H[PW_LO_OUT];
   const uint32_t in_phys[4] = {H[PW_IN_PHYS], H[PW_IN_PHYS + 1], H[PW_IN_PHYS + 2], H[PW_IN_PHYS + 3]};
   const uint32_t in_gphys[4] = {H[PW_IN_GPHYS], H[PW_IN_GPHYS + 1], H[PW_IN_GPHYS + 2], H[PW_IN_GPHYS + 3]};
-  const uint32_t out_lds[4] = {H[PW_OUT_LDS], H[PW_OUT_LDS + 1], H[PW_OUT_LDS + 2], H[PW_OUT_LDS + 3]};
+  uint32_t in_mask[8], in_gmask[8], out_mask[8], out_gmask[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    in_mask[i] = H[PW_IN_MASK + i]; in_gmask[i] = H[PW_IN_GMASK + i];
+    out_mask[i] = H[PW_OUT_MASK + i]; out_gmask[i] = H[PW_OUT_GMASK + i];
+  }
   const uint32_t out_phys[4] = {H[PW_OUT_PHYS], H[PW_OUT_PHYS + 1], H[PW_OUT_PHYS + 2], H[PW_OUT_PHYS + 3]};
   const uint32_t out_gphys[4] = {H[PW_OUT_GPHYS], H[PW_OUT_GPHYS + 1], H[PW_OUT_GPHYS + 2], H[PW_OUT_GPHYS + 3]};
   const uint32_t t = threadIdx.x, T = blockDim.x;
@@ -195,9 +222,14 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
     const uint32_t gin = deposit16(g, 0, n - k, in_gphys);
     const double2* __restrict__ src = in + b * state_stride + gin;
     const uint32_t thr = (t & ((1u << lo_in) - 1u)) | deposit16(t, lo_in, kt, in_phys);
-    uint32_t ipos[4];                 // phys-in position of the index bits supplied by the iteration count
+    uint32_t ipos[4], imask[4];       // phys-in position / LDS slot mask of the index bits supplied by the iteration count
 #pragma unroll
-    for (int m = 0; m < 4; ++m) ipos[m] = (kt + m < k) ? byte16(in_phys, (uint32_t)(kt + m)) : 0u;
+    for (int m = 0; m < 4; ++m) {
+      ipos[m] = (kt + m < k) ? byte16(in_phys, (uint32_t)(kt + m)) : 0u;
+      imask[m] = (kt + m < k) ? half16_dyn(in_mask, kt + m) : 0u;
+    }
+    // swizzled LDS slot of element u = slot_t ^ (iteration part): the CNOTs at the head of the pass are folded in
+    const uint32_t slot_t = xor_map16(t, kt, in_mask) ^ xor_map16(g, n - k, in_gmask);
     if (FULL) {
       double2 v[MAX_TILE_ITERS];      // every load of the tile is in flight before the first LDS write
 #pragma unroll
@@ -207,12 +239,16 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
         v[i] = src[thr | itp];
       }
 #pragma unroll
-      for (int i = 0; i < MAX_TILE_ITERS; ++i) tile[lds_swizzle(t | ((uint32_t)i << kt))] = v[i];
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+        const uint32_t its = ((i & 1) ? imask[0] : 0u) ^ ((i & 2) ? imask[1] : 0u) ^ ((i & 4) ? imask[2] : 0u) ^ ((i & 8) ? imask[3] : 0u);
+        tile[slot_t ^ its] = v[i];
+      }
     } else {
       for (int i = 0; i < niter; ++i) {
         const uint32_t itp = ((i & 1) ? 1u << ipos[0] : 0u) | ((i & 2) ? 1u << ipos[1] : 0u) |
                              ((i & 4) ? 1u << ipos[2] : 0u) | ((i & 8) ? 1u << ipos[3] : 0u);
-        tile[lds_swizzle(t | ((uint32_t)i << kt))] = src[thr | itp];
+        const uint32_t its = ((i & 1) ? imask[0] : 0u) ^ ((i & 2) ? imask[1] : 0u) ^ ((i & 4) ? imask[2] : 0u) ^ ((i & 8) ? imask[3] : 0u);
+        tile[slot_t ^ its] = src[thr | itp];
       }
     }
   }
@@ -302,23 +338,22 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
   // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order ---------------
   if (t < ksize && !(dbg & 8)) {
     const uint32_t gout = deposit16(g, 0, n - k, out_gphys);
-    const uint32_t thr_l = deposit16(t, 0, kt, out_lds);
+    const uint32_t thr_l = xor_map16(t, kt, out_mask) ^ xor_map16(g, n - k, out_gmask);   // tail CNOTs folded in
     const uint32_t thr_p = (t & ((1u << lo_out) - 1u)) | deposit16(t, lo_out, kt, out_phys);
     uint32_t lpos[4], ppos[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      lpos[m] = (kt + m < k) ? byte16(out_lds, (uint32_t)(kt + m)) : 0u;
+      lpos[m] = (kt + m < k) ? half16_dyn(out_mask, kt + m) : 0u;
       ppos[m] = (kt + m < k) ? byte16(out_phys, (uint32_t)(kt + m)) : 0u;
     }
     const bool fin = flags & PASS_FINAL;
     double2* __restrict__ dst = out + b * state_stride + gout;
     double* __restrict__ pdst = probs + (b << n) + gout;
     auto move_out = [&](int i) {
-      const uint32_t it_l = ((i & 1) ? 1u << lpos[0] : 0u) | ((i & 2) ? 1u << lpos[1] : 0u) |
-                            ((i & 4) ? 1u << lpos[2] : 0u) | ((i & 8) ? 1u << lpos[3] : 0u);
+      const uint32_t it_l = ((i & 1) ? lpos[0] : 0u) ^ ((i & 2) ? lpos[1] : 0u) ^ ((i & 4) ? lpos[2] : 0u) ^ ((i & 8) ? lpos[3] : 0u);
       const uint32_t it_p = ((i & 1) ? 1u << ppos[0] : 0u) | ((i & 2) ? 1u << ppos[1] : 0u) |
                             ((i & 4) ? 1u << ppos[2] : 0u) | ((i & 8) ? 1u << ppos[3] : 0u);
-      const double2 v = tile[lds_swizzle(thr_l | it_l)];
+      const double2 v = tile[thr_l ^ it_l];
       if (fin) pdst[thr_p | it_p] = v.x * v.x + v.y * v.y;
       else dst[thr_p | it_p] = v;
     };

@@ -430,14 +430,69 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       put_byte(PW_IN_GPHYS, m, (i > 0) ? layout[i - 1][P.global[m]] : (n - 1 - P.global[m]));
       put_byte(PW_OUT_GPHYS, m, layout[i][P.global[m]]);
     }
+    // CNOTs at the head / tail of the pass that commute past everything before / after them in the pass are
+    // folded into the tile load / store addressing (GF(2)-linear maps of the tile index): no LDS round trip.
+    std::vector<int> lead, core, trail;
+    {
+      std::vector<char> touched(n, 0);
+      std::vector<int> mid;
+      for (int idx : P.ops) {
+        const Op& o = ops[idx];
+        if (!(flags & PASS_INIT) && o.kind == K_CX && !touched[o.a] && !touched[o.b]) { lead.push_back(idx); continue; }
+        touched[o.a] = 1; if (o.b >= 0) touched[o.b] = 1;
+        mid.push_back(idx);
+      }
+      std::fill(touched.begin(), touched.end(), 0);
+      std::vector<int> trail_rev, core_rev;
+      for (size_t q = mid.size(); q-- > 0;) {
+        const Op& o = ops[mid[q]];
+        if (o.kind == K_CX && !touched[o.a] && !touched[o.b]) { trail_rev.push_back(mid[q]); continue; }
+        touched[o.a] = 1; if (o.b >= 0) touched[o.b] = 1;
+        core_rev.push_back(mid[q]);
+      }
+      core.assign(core_rev.rbegin(), core_rev.rend());
+      trail.assign(trail_rev.rbegin(), trail_rev.rend());
+    }
+    struct LExpr { uint32_t l, g; };   // slot bit = parity(l & tile index) ^ parity(g & workgroup index)
+    auto compose_lin = [&](const std::vector<int>& seq, bool reverse) {
+      std::vector<LExpr> ex(k);
+      for (int b2 = 0; b2 < k; ++b2) ex[b2] = LExpr{1u << b2, 0u};
+      for (size_t q = 0; q < seq.size(); ++q) {
+        const Op& o = ops[seq[reverse ? seq.size() - 1 - q : q]];
+        const LExpr ce = ldspos[o.a] >= 0 ? ex[ldspos[o.a]] : LExpr{0u, 1u << gpos[o.a]};
+        ex[ldspos[o.b]].l ^= ce.l; ex[ldspos[o.b]].g ^= ce.g;
+      }
+      return ex;
+    };
+    auto put_half = [&](int table, int j, uint32_t value) { W[base + table + (j >> 1)] |= (value & 0xffffu) << (16 * (j & 1)); };
+    {
+      const std::vector<LExpr> fin = compose_lin(lead, false);     // slot = pi_pre(u)
+      for (int j = 0; j < k; ++j) {
+        uint32_t col = 0;
+        for (int b2 = 0; b2 < k; ++b2) col |= ((fin[b2].l >> j) & 1u) << b2;
+        put_half(PW_IN_MASK, j, lds_swizzle(col));
+      }
+      for (int m = 0; m < n - k; ++m) {
+        uint32_t col = 0;
+        for (int b2 = 0; b2 < k; ++b2) col |= ((fin[b2].g >> m) & 1u) << b2;
+        put_half(PW_IN_GMASK, m, lds_swizzle(col));
+      }
+    }
     {  // out enumeration: out_low wires first (phys bit j), then the other local wires by LDS position
+      const std::vector<LExpr> fout = compose_lin(trail, true);    // slot = pi_post^{-1}(y)
+      auto out_col = [&](int q) { uint32_t col = 0; for (int b2 = 0; b2 < k; ++b2) col |= ((fout[b2].l >> q) & 1u) << b2; return lds_swizzle(col); };
       std::vector<char> isl(n, 0);
       int j = 0;
-      for (int w : P.out_low) { put_byte(PW_OUT_LDS, j, ldspos[w]); put_byte(PW_OUT_PHYS, j, layout[i][w]); isl[w] = 1; ++j; }
+      for (int w : P.out_low) { put_half(PW_OUT_MASK, j, out_col(ldspos[w])); put_byte(PW_OUT_PHYS, j, layout[i][w]); isl[w] = 1; ++j; }
       for (int q = 0; q < k; ++q) {
         int w = P.lds_wire[q];
         if (isl[w]) continue;
-        put_byte(PW_OUT_LDS, j, q); put_byte(PW_OUT_PHYS, j, layout[i][w]); ++j;
+        put_half(PW_OUT_MASK, j, out_col(q)); put_byte(PW_OUT_PHYS, j, layout[i][w]); ++j;
+      }
+      for (int m = 0; m < n - k; ++m) {
+        uint32_t col = 0;
+        for (int b2 = 0; b2 < k; ++b2) col |= ((fout[b2].g >> m) & 1u) << b2;
+        put_half(PW_OUT_GMASK, m, lds_swizzle(col));
       }
     }
     // ---- stages ----
@@ -447,7 +502,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     //   -> CNOTs of phase 3 folded into the LDS write address, sign of phase 4 evaluated on the
     //      permuted index.  A CNOT whose target is a register wire only permutes amplitudes inside
     //      the 2^r-element group a thread owns, so the in-place write-back needs no extra barrier.
-    std::vector<int> pool = P.ops, rest;
+    std::vector<int> pool = core, rest;
     uint32_t nstages = 0;
     while (!pool.empty()) {
       StageSel sel;

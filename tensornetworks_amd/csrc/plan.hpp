@@ -46,22 +46,34 @@ enum PlanHeader : int {
 //   [0] wire  [1] n_elem  [2+2e] kind_e  [3+2e] param_e   (e < FUSED_MAX_ELEMS), applied e = 0 first
 constexpr int FUSED_MAX_ELEMS = 4;
 constexpr int FUSED_WORDS = 2 + 2 * FUSED_MAX_ELEMS;
-// pass descriptor: a 32-word header the kernel fetches with two wide scalar loads; bit positions are
-// packed one per byte (16 bytes = 4 words per table, so k <= 16 and n - k <= 16)
+// pass descriptor: a 64-word header the kernel fetches with four wide scalar loads.  Bit positions are
+// packed one per byte (16 bytes = 4 words per table, so k <= 16 and n - k <= 16), LDS slot masks one per
+// 16 bits (8 words per table).
+//
+// Tile <-> HBM mapping.  Load: element u of the load enumeration (bit j of u = LDS/tile bit j of the pass's
+// input frame) is read from phys-in address  sum_j bit_j(u) << IN_PHYS[j]  |  sum_m bit_m(g) << IN_GPHYS[m]
+// and stored at the SWIZZLED LDS slot  xor_j bit_j(u) IN_MASK[j]  ^  xor_m bit_m(g) IN_GMASK[m].
+// Without folded CNOTs IN_MASK[j] = lds_swizzle(1 << j); CNOTs at the head of the pass (targets tile-local)
+// are GF(2)-linear maps of the tile index and are folded into these masks -- they cost nothing.
+// Store: element v of the out enumeration is read from slot  xor_j bit_j(v) OUT_MASK[j] ^ xor_m bit_m(g) OUT_GMASK[m]
+// (CNOTs at the tail of the pass folded in) and written to  sum_j bit_j(v) << OUT_PHYS[j] | sum_m bit_m(g) << OUT_GPHYS[m].
 enum PassWords : int {
   PW_FLAGS = 0, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS, PW_RESERVED,
-  PW_IN_PHYS = 8,       // [16 bytes] phys-in bit position of LDS bit j
-  PW_IN_GPHYS = 12,     // [16 bytes] phys-in bit position of workgroup-index bit m
-  PW_OUT_LDS = 16,      // [16 bytes] LDS bit position of out-enumeration bit j
-  PW_OUT_PHYS = 20,     // [16 bytes] phys-out bit position of out-enumeration bit j
-  PW_OUT_GPHYS = 24,    // [16 bytes] phys-out bit position of workgroup-index bit m
-  PW_HEADER_WORDS = 32,
-  PW_WIRE_OF_LDS = 32,  // [32 words] wire held by LDS bit j        (informational / emulator)
-  PW_WIRE_OF_G = 64,    // [32 words] wire held by workgroup bit m  (informational / emulator)
-  PW_MATS = 96,         // [MAX_STAGES * 2 words] fused gate index of (stage s, register bit i), 16 bits each:
+  PW_IN_PHYS = 8,       // [16 bytes]
+  PW_IN_GPHYS = 12,     // [16 bytes]
+  PW_OUT_PHYS = 16,     // [16 bytes]
+  PW_OUT_GPHYS = 20,    // [16 bytes]
+  PW_IN_MASK = 24,      // [16 x 16 bit]
+  PW_IN_GMASK = 32,     // [16 x 16 bit]
+  PW_OUT_MASK = 40,     // [16 x 16 bit]
+  PW_OUT_GMASK = 48,    // [16 x 16 bit]
+  PW_HEADER_WORDS = 64,
+  PW_WIRE_OF_LDS = 64,  // [32 words] wire held by LDS bit j        (informational / emulator)
+  PW_WIRE_OF_G = 96,    // [32 words] wire held by workgroup bit m  (informational / emulator)
+  PW_MATS = 128,        // [MAX_STAGES * 2 words] fused gate index of (stage s, register bit i), 16 bits each:
                         //   word PW_MATS + 2 s + (i >> 1); the workgroup copies these matrices of ITS circuit
                         //   into LDS (after the tile) while the tile loads are in flight
-  PW_STAGES = 96 + 2 * 32
+  PW_STAGES = 128 + 2 * 32
 };
 constexpr int MAX_STAGES = 32;          // stages per pass
 constexpr int STAGE_MATS_BYTES = 4 * 64; // LDS bytes of one stage's four 2x2 complex matrices

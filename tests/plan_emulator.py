@@ -13,8 +13,8 @@ from oracle import circuit as oc
 PH_N, PH_K, PH_NPASSES, PH_NFUSED, PH_NPARAMS, PH_OFF_FUSED, PH_OFF_PASSTAB, PH_TOTAL, PH_THREADS, PH_R, PH_NGATES = range(1, 12)
 FUSED_WORDS = 10
 PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
-PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_LDS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_STAGES = 8, 12, 16, 20, 24, 32, 64, 160
-PW_MATS = 96
+PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_IN_MASK, PW_IN_GMASK, PW_OUT_MASK, PW_OUT_GMASK = 8, 12, 16, 20, 24, 32, 40, 48
+PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_MATS, PW_STAGES = 64, 96, 128, 192
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
 STAGE_HDR_WORDS = 48
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
@@ -39,6 +39,18 @@ def fused_matrices(W, theta):
 def tbyte(P, table, j):
     """Entry j of a byte-packed 16-entry table of the pass header."""
     return (int(P[table + (j >> 2)]) >> (8 * (j & 3))) & 0xFF
+
+
+def thalf(P, table, j):
+    """Entry j of a 16-bit-packed 16-entry table of the pass header."""
+    return (int(P[table + (j >> 1)]) >> (16 * (j & 1))) & 0xFFFF
+
+
+def xor_map(v, nbits, P, table):
+    o = np.zeros_like(v)
+    for j in range(nbits):
+        o ^= ((v >> j) & 1) * thalf(P, table, j)
+    return o
 
 
 def swz(l):
@@ -99,7 +111,12 @@ def run_plan(W, mats, state_in=None):
                     phys |= ((u >> j) & 1) << tbyte(P, PW_IN_PHYS, j)
                 for m in range(n - k):
                     phys |= ((g >> m) & 1) << tbyte(P, PW_IN_GPHYS, m)
-                tile = buf[phys]
+                # LDS slot of each loaded element: head CNOTs of the pass are folded into the slot masks
+                gvec = np.full(ksize, g, dtype=np.int64)
+                slot = swz_inv(xor_map(u, k, P, PW_IN_MASK) ^ xor_map(gvec, n - k, P, PW_IN_GMASK))
+                assert np.array_equal(np.sort(slot), np.arange(ksize))
+                tile = np.zeros(ksize, dtype=np.complex128)
+                tile[slot] = buf[phys]
             S = P[PW_STAGES:]
             for si in range(nst):
                 # the per-pass matrix table (what the kernel stages into LDS) must agree with the stage header
@@ -167,10 +184,10 @@ def run_plan(W, mats, state_in=None):
                 S = S[nwords:]
             # store
             v = np.arange(ksize, dtype=np.int64)
-            lds = np.zeros(ksize, dtype=np.int64)
+            gvec = np.full(ksize, g, dtype=np.int64)
+            lds = swz_inv(xor_map(v, k, P, PW_OUT_MASK) ^ xor_map(gvec, n - k, P, PW_OUT_GMASK))   # tail CNOTs folded in
             phys = np.zeros(ksize, dtype=np.int64)
             for j in range(k):
-                lds |= ((v >> j) & 1) << tbyte(P, PW_OUT_LDS, j)
                 phys |= ((v >> j) & 1) << tbyte(P, PW_OUT_PHYS, j)
             for m in range(n - k):
                 phys |= ((g >> m) & 1) << tbyte(P, PW_OUT_GPHYS, m)
