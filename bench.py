@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--no-gate-bench", action="store_true")
     ap.add_argument("--tile-bits", type=int, default=0)
     ap.add_argument("--debug-flags", type=int, default=0, help="timing-only kernel ablations (results invalid)")
+    ap.add_argument("--wgs-per-cu", type=int, default=-1, help="generic circuit kernel: persistent workgroups per CU (0 = one per tile)")
+    ap.add_argument("--fast-path", type=int, default=-1, help="0: force the generic circuit kernel (A/B against the fast one)")
+    ap.add_argument("--fast-wgs-per-cu", type=int, default=-1, help="fast circuit kernel: persistent workgroups per CU (0 = occupancy query)")
     ap.add_argument("--overlap", type=int, default=-1, help="1/0: contraction on a second stream beside the shifted circuits")
     args = ap.parse_args()
 
@@ -147,6 +150,12 @@ def main():
         backend.set_option(dev, "tile_bits", args.tile_bits)
     if args.debug_flags:
         backend.set_option(dev, "debug_flags", args.debug_flags)
+    if args.wgs_per_cu >= 0:
+        backend.set_option(dev, "workgroups_per_cu", args.wgs_per_cu)
+    if args.fast_path >= 0:
+        backend.set_option(dev, "fast_path", args.fast_path)
+    if args.fast_wgs_per_cu >= 0:
+        backend.set_option(dev, "fast_workgroups_per_cu", args.fast_wgs_per_cu)
     bn, lat, obs, x = synthetic_network(n, seed=0)
     torch.manual_seed(0)
     vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,

@@ -201,6 +201,13 @@ int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double m
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
                                size_t cap_words);
 
+/* The tables the fast pass kernel reads (one entry per stage, tile and thread: LDS slots with the CNOT
+ * index maps folded in, CZ sign bits), derived on the host from the plan above; pass_off_out[i] = word
+ * offset of pass i's header.  Returns the number of words, 0 when the plan runs on the generic kernel
+ * (tiles below 2^10 amplitudes), -1 when unsupported.  Host only; used by the CPU tests. */
+long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
+                                    size_t cap_words, uint32_t* pass_off_out, int cap_passes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,8 @@ _PROTOS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_clip_cast_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_plan_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t]),
+    "bornvi_plan_fast_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
+                                                 C.POINTER(C.c_uint32), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -106,6 +108,22 @@ def plan_words(ansatz_id, n, layers, tile_bits=0):
     buf = (C.c_uint32 * need)()
     L.bornvi_plan_describe(ansatz_id, n, layers, tile_bits, buf, need)
     return np.frombuffer(buf, dtype=np.uint32).copy()
+
+
+def plan_fast_words(ansatz_id, n, layers, tile_bits=0):
+    """Fast-path tables of a plan: (words, pass offsets), or (None, None) when the plan is not eligible."""
+    import numpy as np
+    L = lib()
+    need = L.bornvi_plan_fast_describe(ansatz_id, n, layers, tile_bits, None, 0, None, 0)
+    if need < 0:
+        raise BornviError("bornvi_plan_fast_describe: unsupported configuration")
+    if need == 0:
+        return None, None
+    npass = int(plan_words(ansatz_id, n, layers, tile_bits)[3])
+    buf = (C.c_uint32 * need)()
+    offs = (C.c_uint32 * npass)()
+    L.bornvi_plan_fast_describe(ansatz_id, n, layers, tile_bits, buf, need, offs, npass)
+    return np.frombuffer(buf, dtype=np.uint32).copy(), np.frombuffer(offs, dtype=np.uint32).copy()
 
 
 class Handle:

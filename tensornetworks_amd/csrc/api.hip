@@ -20,7 +20,14 @@ namespace {
 struct DevPlan {
   Plan plan;
   uint32_t* d_words = nullptr;
+  // fast path (plan.hpp: build_fast_tables): per-(stage, tile, thread) tables + persistent grid size
+  FastTables fast;
+  uint32_t* d_fast = nullptr;
+  int fast_workgroups = 0;   // co-resident workgroups of circuit_pass_fast_kernel on the whole device
 };
+
+constexpr size_t FAST_TABLE_MAX_BYTES = (size_t)256 << 20;
+constexpr size_t MAX_LDS_BYTES = 160 * 1024;   // per CU and per workgroup on gfx950
 
 thread_local std::string g_create_error;
 
@@ -35,6 +42,10 @@ struct bornvi_ctx {
   std::map<std::tuple<int, int, int>, std::unique_ptr<DevPlan>> plans;  // (ansatz | -1 = kron, n, layers)
   size_t max_lds_prepared = 0;
   int debug_flags = 0;  // timing-only ablations of circuit_pass_kernel (results are WRONG when non-zero)
+  int num_cus = 256;    // multiProcessorCount
+  int wgs_per_cu = 0;   // generic kernel: > 0 = persistent grid of num_cus * wgs_per_cu workgroups; 0 = one per tile
+  int fast_path = 1;    // 1: circuit_pass_fast_kernel where the plan is eligible; 0: always the generic kernel
+  int fast_wgs_per_cu = 0;  // fast kernel: 0 = what the occupancy query admits
 };
 
 namespace {
@@ -67,9 +78,29 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
     HIPCHK(h, prepare_circuit_kernel(dp->plan.lds_bytes()));
     h->max_lds_prepared = dp->plan.lds_bytes();
   }
+  // fast path only when the tile, the matrices and one tile row of the stage tables fit the CU's 160 KiB of LDS
+  if (build_fast_tables(dp->plan, FAST_TABLE_MAX_BYTES, dp->fast) &&
+      dp->plan.fast_lds_bytes(dp->fast.any_sign) <= MAX_LDS_BYTES) {
+    HIPCHK(h, hipMalloc((void**)&dp->d_fast, dp->fast.words.size() * sizeof(uint32_t)));
+    HIPCHK(h, hipMemcpy(dp->d_fast, dp->fast.words.data(), dp->fast.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const size_t flds = dp->plan.fast_lds_bytes(dp->fast.any_sign);
+    if (flds > h->max_lds_prepared) {
+      HIPCHK(h, prepare_circuit_kernel(flds));
+      h->max_lds_prepared = flds;
+    }
+    dp->fast_workgroups = circuit_fast_workgroups_per_cu(1 << (dp->plan.k - 4), flds) * h->num_cus;
+    std::vector<uint32_t>().swap(dp->fast.words);   // the host copy is no longer needed (pass_off is)
+  }
   *out = dp.get();
   h->plans[key] = std::move(dp);
   return BORNVI_OK;
+}
+
+void free_plan(DevPlan* dp) {
+  if (!dp) return;
+  if (dp->d_words) (void)hipFree(dp->d_words);
+  if (dp->d_fast) (void)hipFree(dp->d_fast);
+  dp->d_words = dp->d_fast = nullptr;
 }
 
 // bytes one circuit needs in the workspace: its fused-gate matrices + two ping-pong states
@@ -88,7 +119,14 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
   for (int i = 0; i < p.n_passes; ++i) {
     const bool last = (i == p.n_passes - 1);
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
-    HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, p.lds_bytes(), bc, in, out, final_probs, gates, gate_stride, h->debug_flags, st));
+    if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
+      const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * h->num_cus : dp->fast_workgroups;
+      HIPCHK(h, launch_circuit_pass_fast(dp->d_words, p.pass_off[i], dp->d_fast, dp->fast.pass_off[i], p.n, p.k,
+                                         p.fast_lds_bytes(dp->fast.any_sign), bc, in, out, final_probs, gates, gate_stride, wgs,
+                                         p.fast_lds_tab_off(), h->debug_flags, st));
+    } else {
+      HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, p.lds_bytes(), bc, in, out, final_probs, gates, gate_stride, h->wgs_per_cu * h->num_cus, h->debug_flags, st));
+    }
     in = out;
   }
   return BORNVI_OK;
@@ -152,14 +190,16 @@ int bornvi_create(int device_ordinal, bornvi_handle* out) {
   bornvi_ctx* h = new (std::nothrow) bornvi_ctx();
   if (!h) { g_create_error = "out of host memory"; return BORNVI_ERR_INVALID; }
   h->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+    h->num_cus = prop.multiProcessorCount;
   *out = h;
   return BORNVI_OK;
 }
 
 void bornvi_destroy(bornvi_handle h) {
   if (!h) return;
-  for (auto& kv : h->plans)
-    if (kv.second && kv.second->d_words) (void)hipFree(kv.second->d_words);
+  for (auto& kv : h->plans) free_plan(kv.second.get());
   delete h;
 }
 
@@ -168,6 +208,17 @@ const char* bornvi_last_error(bornvi_handle h) { return h ? h->err.c_str() : g_c
 int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   if (!h || !name) return BORNVI_ERR_INVALID;
   if (!std::strcmp(name, "debug_flags")) { h->debug_flags = (int)value; return BORNVI_OK; }
+  if (!std::strcmp(name, "workgroups_per_cu")) {
+    if (value < 0 || value > 16) return fail(h, BORNVI_ERR_INVALID, "option value out of range");
+    h->wgs_per_cu = (int)value;
+    return BORNVI_OK;
+  }
+  if (!std::strcmp(name, "fast_path")) { h->fast_path = value ? 1 : 0; return BORNVI_OK; }
+  if (!std::strcmp(name, "fast_workgroups_per_cu")) {
+    if (value < 0 || value > 16) return fail(h, BORNVI_ERR_INVALID, "option value out of range");
+    h->fast_wgs_per_cu = (int)value;
+    return BORNVI_OK;
+  }
   PlanOptions o = h->opt;
   if (!std::strcmp(name, "tile_bits")) { o.kmax = (int)value; o.kmulti = (int)value; }
   else if (!std::strcmp(name, "tile_bits_multi")) o.kmulti = (int)value;
@@ -178,8 +229,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
       (o.max_threads & (o.max_threads - 1)))
     return fail(h, BORNVI_ERR_INVALID, "option value out of range");
   h->opt = o;
-  for (auto& kv : h->plans)
-    if (kv.second && kv.second->d_words) (void)hipFree(kv.second->d_words);
+  for (auto& kv : h->plans) free_plan(kv.second.get());
   h->plans.clear();
   return BORNVI_OK;
 }
@@ -437,6 +487,25 @@ long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uin
     std::memcpy(out, p.words.data(), c * sizeof(uint32_t));
   }
   return (long long)p.words.size();
+}
+
+long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words,
+                                    uint32_t* pass_off_out, int cap_passes) {
+  PlanOptions opt;
+  if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
+  Plan p;
+  std::string msg;
+  const bool ok = (ansatz == -1) ? make_kron_plan(n, opt, p, msg) : make_plan(ansatz, n, layers, opt, p, msg);
+  if (!ok) return -1;
+  FastTables ft;
+  if (!build_fast_tables(p, FAST_TABLE_MAX_BYTES, ft)) return 0;
+  if (out) {
+    const size_t c = ft.words.size() < cap_words ? ft.words.size() : cap_words;
+    std::memcpy(out, ft.words.data(), c * sizeof(uint32_t));
+  }
+  if (pass_off_out)
+    for (int i = 0; i < cap_passes && i < (int)ft.pass_off.size(); ++i) pass_off_out[i] = ft.pass_off[i];
+  return (long long)ft.words.size();
 }
 
 }  // extern "C"

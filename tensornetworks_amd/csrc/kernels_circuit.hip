@@ -172,7 +172,7 @@ template <bool FULL, bool DEBUG>
 __global__ __launch_bounds__(512) void circuit_pass_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const double2* __restrict__ in,
     double2* __restrict__ out, double* __restrict__ probs, const double* __restrict__ gates,
-    long long gate_stride, long long state_stride, int dbg_arg) {
+    long long gate_stride, long long state_stride, long long total_tiles, int dbg_arg) {
   // timing-only ablation flags exist only in the DEBUG instantiation: in the production kernel every
   // `dbg` test folds away (as run-time tests they cost a scalar branch per LDS access)
   const int dbg = DEBUG ? dbg_arg : 0;
@@ -198,11 +198,18 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
   const uint32_t t = threadIdx.x, T = blockDim.x;
   const int tau = 31 - __clz((int)T);
   const int kt = tau < k ? tau : k;  // index bits supplied by the thread id
-  const uint32_t g = blockIdx.x;
-  const long long b = blockIdx.y;
   const uint32_t ksize = 1u << k;
   const int niter = 1 << (k - kt);    // <= MAX_TILE_ITERS (checked by the planner: threads >= 2^(k-4))
   double2* __restrict__ mats = tile + ksize;   // [nstages][4 register bits][4 double2] fused matrices of circuit b
+  const int gbits = n - k;
+
+  // A workgroup walks over tiles T = blockIdx.x, blockIdx.x + gridDim.x, ... of the flattened (circuit, tile)
+  // space.  With gridDim.x == total_tiles every workgroup handles one tile; with a PERSISTENT grid (as many
+  // workgroups as are co-resident) the header is fetched once per workgroup and a tile's write-back drains
+  // while the next tile's loads are already in flight.
+  for (long long Tcur = blockIdx.x; Tcur < total_tiles; Tcur += gridDim.x) {
+  const uint32_t g = (uint32_t)(Tcur & ((1ll << gbits) - 1));
+  const long long b = Tcur >> gbits;
 
   // ---- this circuit's fused matrices for every stage of the pass -> LDS (one 16-byte piece per thread;
   // they were written by build_gates_kernel on other CUs, i.e. they come from far memory: fetch them once,
@@ -364,6 +371,319 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
       for (int i = 0; i < niter; ++i) move_out(i);
     }
   }
+  if (Tcur + gridDim.x < total_tiles) __syncthreads();   // the tile and the matrices are overwritten by the next tile
+  }  // tile loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast pass kernel (tiles of 2^10 .. 2^13 amplitudes, 16 per thread).  Same plan, same arithmetic model as
+// circuit_pass_kernel, restructured around what the profile showed:
+//   * PERSISTENT workgroups walk over the (circuit, tile) space; while a tile is in its stage loop the NEXT
+//     tile's amplitudes and matrices are already in flight into registers and the previous tile's stores drain,
+//     so the HBM phases overlap the FMA/LDS phases inside one workgroup (and workgroup dispatch, header and
+//     index-map set-up are paid once per workgroup, not once per tile);
+//   * every index-dependent quantity of a stage (LDS slots with the CNOT flips folded in, CZ sign bits) comes
+//     from planner tables RW / SG (plan.hpp, build_fast_tables): one coalesced 4-byte load per thread per
+//     stage, fetched one stage ahead; the 16 slot addresses follow from 4 basis offsets by one xor each;
+//   * the 2x2 complex gate updates its amplitude pair IN PLACE (12 partial-sum ops into 4 temporaries, then 4
+//     final FMAs that each overwrite the operand they read last): the compiler's version needed 32 register
+//     moves per gate to merge the conditional gate back into the amplitude registers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gate_pair_inplace(double& x0r, double& x0i, double& x1r, double& x1i,
+                                                  const double (&U)[8]) {
+  double t0, t1, t2, t3;
+  asm("v_mul_f64 %4, %9, %1\n\t"          // t0 = U1 x0i
+      "v_mul_f64 %5, %9, %0\n\t"          // t1 = U1 x0r
+      "v_mul_f64 %6, %13, %1\n\t"         // t2 = U5 x0i
+      "v_mul_f64 %7, %13, %0\n\t"         // t3 = U5 x0r
+      "v_fma_f64 %4, %10, %2, -%4\n\t"    // t0 = U2 x1r - U1 x0i
+      "v_fma_f64 %5, %10, %3, %5\n\t"     // t1 = U2 x1i + U1 x0r
+      "v_fma_f64 %6, %12, %0, -%6\n\t"    // t2 = U4 x0r - U5 x0i
+      "v_fma_f64 %7, %12, %1, %7\n\t"     // t3 = U4 x0i + U5 x0r
+      "v_fma_f64 %4, -%11, %3, %4\n\t"    // t0 -= U3 x1i
+      "v_fma_f64 %5, %11, %2, %5\n\t"     // t1 += U3 x1r
+      "v_fma_f64 %6, -%15, %3, %6\n\t"    // t2 -= U7 x1i
+      "v_fma_f64 %7, %15, %2, %7\n\t"     // t3 += U7 x1r
+      "v_fma_f64 %0, %8, %0, %4\n\t"      // x0r = U0 x0r + t0
+      "v_fma_f64 %1, %8, %1, %5\n\t"      // x0i = U0 x0i + t1
+      "v_fma_f64 %2, %14, %2, %6\n\t"     // x1r = U6 x1r + t2
+      "v_fma_f64 %3, %14, %3, %7"         // x1i = U6 x1i + t3
+      : "+v"(x0r), "+v"(x0i), "+v"(x1r), "+v"(x1i), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(U[0]), "v"(U[1]), "v"(U[2]), "v"(U[3]), "v"(U[4]), "v"(U[5]), "v"(U[6]), "v"(U[7]));
+}
+
+__device__ __forceinline__ void load_u(const double2* __restrict__ Um, double (&U)[8]) {
+  const double2 u00 = Um[0], u01 = Um[1], u10 = Um[2], u11 = Um[3];
+  U[0] = u00.x; U[1] = u00.y; U[2] = u01.x; U[3] = u01.y; U[4] = u10.x; U[5] = u10.y; U[6] = u11.x; U[7] = u11.y;
+}
+
+template <int I>
+__device__ __forceinline__ void op_u1_inplace(double (&ar)[16], double (&ai)[16], const double (&U)[8]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j & (1 << I)) continue;
+    gate_pair_inplace(ar[j], ai[j], ar[j | (1 << I)], ai[j | (1 << I)], U);
+  }
+}
+
+// flips the sign of slot j where bit j of `m` is set (xor on the sign bit of both components)
+__device__ __forceinline__ void apply_sign_bits(uint32_t m, double (&ar)[16], double (&ai)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int sw = (int)((m << (31 - j)) & 0x80000000u);
+    ar[j] = __hiloint2double(__double2hiint(ar[j]) ^ sw, __double2loint(ar[j]));
+    ai[j] = __hiloint2double(__double2hiint(ai[j]) ^ sw, __double2loint(ai[j]));
+  }
+}
+
+// One stage on the 16 amplitudes a thread owns, specialised on the number of fused gates (the planner puts
+// them on register bits 0 .. NG-1) and on the two CZ sign products: straight-line code, no merges of the
+// 64 amplitude registers (conditional gates cost ~100 register copies per stage in the generic kernel).
+template <int NG, bool PRE, bool POST, bool DEBUG>
+__device__ __forceinline__ void stage_body(double2* __restrict__ tile, const double2* __restrict__ Us, uint32_t my_rw,
+                                           uint32_t my_sg, const uint32_t (&G)[10], int dbg) {
+  double ar[16], ai[16];
+  {
+    uint32_t ra[16];   // byte addresses of the 16 slots: GF(2)-linear in the slot number
+    ra[0] = (my_rw & 0xffffu) << 4;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const int low = j & (-j), bit = (low == 1) ? 0 : (low == 2) ? 1 : (low == 4) ? 2 : 3;
+      ra[j] = ra[j ^ low] ^ G[FS_RB + bit];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (!(DEBUG && (dbg & 2))) {
+        const double2 x = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tile) + ra[j]);
+        ar[j] = x.x; ai[j] = x.y;
+      } else { ar[j] = (double)(ra[j] + j); ai[j] = 0.0; }
+    }
+  }
+  if (PRE) apply_sign_bits(my_sg & 0xffffu, ar, ai);
+  if (!(DEBUG && (dbg & 1))) {
+    double U[8];
+    if (NG > 0) { load_u(Us, U); op_u1_inplace<0>(ar, ai, U); }
+    if (NG > 1) { load_u(Us + 4, U); op_u1_inplace<1>(ar, ai, U); }
+    if (NG > 2) { load_u(Us + 8, U); op_u1_inplace<2>(ar, ai, U); }
+    if (NG > 3) { load_u(Us + 12, U); op_u1_inplace<3>(ar, ai, U); }
+  }
+  if (POST) apply_sign_bits(my_sg >> 16, ar, ai);
+  {
+    uint32_t wa[16];
+    wa[0] = (my_rw >> 16) << 4;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const int low = j & (-j), bit = (low == 1) ? 0 : (low == 2) ? 1 : (low == 4) ? 2 : 3;
+      wa[j] = wa[j ^ low] ^ G[FS_WB + bit];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (!(DEBUG && (dbg & 2))) *reinterpret_cast<double2*>(reinterpret_cast<char*>(tile) + wa[j]) = make_double2(ar[j], ai[j]);
+  }
+  if (DEBUG && (dbg & 2)) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += ar[j] + ai[j];
+    if (acc == 1.2345e300) tile[0] = make_double2(acc, acc);
+  }
+}
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Vector memory ops the COMPILER does not track (it would otherwise drain vmcnt to 0 at every loop merge, i.e.
+// wait for the previous tile's stores and for the next tile's loads in the middle of the pipeline).  The kernel
+// waits by hand: s_waitcnt vmcnt(N) = all but the wave's N youngest vector-memory ops are done, loads and
+// stores counted together in issue order (MI355X_MICROARCH.md, cycle constants).
+__device__ __forceinline__ void async_load16(d2_t& dst, uint32_t byte_off, const void* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void async_store16(uint32_t byte_off, d2_t val, void* base) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+}
+__device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void* base) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+}
+
+template <bool DEBUG>
+__global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
+    const uint32_t* __restrict__ plan, uint32_t pass_off, const uint32_t* __restrict__ fast, uint32_t fast_off,
+    const double2* __restrict__ in, double2* __restrict__ out, double* __restrict__ probs,
+    const double* __restrict__ gates, long long gate_stride, long long state_stride, long long total_tiles,
+    uint32_t lds_tab_off /* double2 units */, int dbg_arg) {
+  const int dbg = DEBUG ? dbg_arg : 0;
+  extern __shared__ double2 tile[];
+  const uint32_t* __restrict__ P = plan + pass_off;
+  const uint32_t* __restrict__ F = fast + fast_off;
+  uint32_t H[PW_HEADER_WORDS];
+#pragma unroll
+  for (int i = 0; i < PW_HEADER_WORDS; ++i) H[i] = P[i];
+  const uint32_t flags = H[PW_FLAGS];
+  const int k = (int)H[PW_K], n = (int)H[PW_N];
+  const int lo_in = (int)H[PW_LO_IN], lo_out = (int)H[PW_LO_OUT];
+  const uint32_t in_phys[4] = {H[PW_IN_PHYS], H[PW_IN_PHYS + 1], H[PW_IN_PHYS + 2], H[PW_IN_PHYS + 3]};
+  const uint32_t in_gphys[4] = {H[PW_IN_GPHYS], H[PW_IN_GPHYS + 1], H[PW_IN_GPHYS + 2], H[PW_IN_GPHYS + 3]};
+  const uint32_t out_phys[4] = {H[PW_OUT_PHYS], H[PW_OUT_PHYS + 1], H[PW_OUT_PHYS + 2], H[PW_OUT_PHYS + 3]};
+  const uint32_t out_gphys[4] = {H[PW_OUT_GPHYS], H[PW_OUT_GPHYS + 1], H[PW_OUT_GPHYS + 2], H[PW_OUT_GPHYS + 3]};
+  uint32_t in_mask[8], in_gmask[8], out_mask[8], out_gmask[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    in_mask[i] = H[PW_IN_MASK + i]; in_gmask[i] = H[PW_IN_GMASK + i];
+    out_mask[i] = H[PW_OUT_MASK + i]; out_gmask[i] = H[PW_OUT_GMASK + i];
+  }
+  const uint32_t t = threadIdx.x, T = blockDim.x;   // T == 2^(k-4): 16 tile elements per thread
+  const int kt = k - 4;
+  const uint32_t ksize = 1u << k;
+  const int gbits = n - k;
+  const int nstages = (int)F[FH_NSTAGES];
+  const uint32_t rw_base = F[FH_RW_BASE], sg_base = F[FH_SG_BASE];
+  const uint32_t sign_pre = F[FH_SIGN_PRE], sign_post = F[FH_SIGN_POST];
+  const bool any_sign = (sign_pre | sign_post) != 0;
+  const uint32_t stage_words = 1u << (n - 4);     // table words per stage
+  double2* __restrict__ mats = tile + ksize;      // [nstages][4 register bits][4 double2]
+  uint32_t* __restrict__ tab_rw = reinterpret_cast<uint32_t*>(tile + lds_tab_off);   // [nstages][T] of this tile row
+  uint32_t* __restrict__ tab_sg = tab_rw + (uint32_t)nstages * T;
+  const bool init = flags & PASS_INIT, fin = flags & PASS_FINAL;
+
+  // ---- per-thread constants of the tile <-> HBM maps (the tile-index parts are wave-uniform, per tile) ----
+  const uint32_t thr_in = ((t & ((1u << lo_in) - 1u)) | deposit16(t, lo_in, kt, in_phys)) << 4;      // bytes
+  const uint32_t slot_in = xor_map16(t, kt, in_mask);
+  const uint32_t slot_out = xor_map16(t, kt, out_mask);
+  const uint32_t thr_out = ((t & ((1u << lo_out) - 1u)) | deposit16(t, lo_out, kt, out_phys)) << (fin ? 3 : 4);
+  uint32_t ipos[4], imask[4], lpos[4], ppos[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    ipos[m] = byte16(in_phys, (uint32_t)(kt + m));
+    imask[m] = half16_dyn(in_mask, kt + m);
+    lpos[m] = half16_dyn(out_mask, kt + m);
+    ppos[m] = byte16(out_phys, (uint32_t)(kt + m));
+  }
+  // the (at most two) 16-byte pieces of the pass's matrices this thread stages per tile
+  int mat_off[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t piece = t + (uint32_t)c * T;
+    mat_off[c] = -1;
+    if (piece < (uint32_t)nstages * 16u) {
+      const uint32_t sm = piece >> 2;
+      const uint32_t w = P[PW_MATS + (sm >> 1)];
+      const uint32_t f = (sm & 1u) ? (w >> 16) : (w & 0xffffu);
+      if (f != 0xffffu) mat_off[c] = (int)((f * 4u + (piece & 3u)) << 4);   // bytes
+    }
+  }
+
+  d2_t v[MAX_TILE_ITERS];   // amplitudes of the NEXT tile (in flight during the current tile's stages)
+  d2_t mp[2];               // its matrices
+#pragma unroll
+  for (int i = 0; i < MAX_TILE_ITERS; ++i) v[i] = (d2_t){0.0, 0.0};
+  mp[0] = mp[1] = (d2_t){0.0, 0.0};
+#define BORNVI_PREFETCH(Tn)                                                                          \
+  do {                                                                                               \
+    const uint32_t gn_ = (uint32_t)((Tn) & ((1ll << gbits) - 1));                                    \
+    const long long bn_ = (Tn) >> gbits;                                                             \
+    const double* gsrc_ = gates + bn_ * gate_stride;                                                 \
+    if (mat_off[0] >= 0) async_load16(mp[0], (uint32_t)mat_off[0], gsrc_);                           \
+    if (mat_off[1] >= 0) async_load16(mp[1], (uint32_t)mat_off[1], gsrc_);                           \
+    if (!init && !(dbg & 4)) {                                                                       \
+      const double2* src_ = in + bn_ * state_stride + deposit16(gn_, 0, gbits, in_gphys);            \
+      _Pragma("unroll") for (int i = 0; i < MAX_TILE_ITERS; ++i) {                                   \
+        const uint32_t itp_ = ((i & 1) ? 16u << ipos[0] : 0u) | ((i & 2) ? 16u << ipos[1] : 0u) |    \
+                              ((i & 4) ? 16u << ipos[2] : 0u) | ((i & 8) ? 16u << ipos[3] : 0u);     \
+        async_load16(v[i], thr_in | itp_, src_);                                                     \
+      }                                                                                              \
+    }                                                                                                \
+  } while (0)
+
+  long long Tcur = blockIdx.x;
+  if (Tcur < total_tiles) BORNVI_PREFETCH(Tcur);
+  uint32_t g_tab = 0xffffffffu;   // tile row whose stage tables are in LDS
+  bool first = true;
+  for (; Tcur < total_tiles; Tcur += gridDim.x) {
+    const uint32_t g = (uint32_t)(Tcur & ((1ll << gbits) - 1));
+    const long long b = Tcur >> gbits;
+    // ---- stage tables of this tile row -> LDS.  The launcher makes the grid a multiple of the tiles per
+    // state whenever it can, so a workgroup keeps its row and this runs once (it drains vmcnt: these are
+    // compiler-tracked loads) ----
+    if (g != g_tab) {
+      g_tab = g;
+      const uint32_t row = (g << kt) + t;
+      for (int s = 0; s < nstages; ++s) {
+        tab_rw[(uint32_t)s * T + t] = fast[rw_base + (uint32_t)s * stage_words + row];
+        if (any_sign) tab_sg[(uint32_t)s * T + t] = fast[sg_base + (uint32_t)s * stage_words + row];
+      }
+    }
+    // ---- the next tile has arrived in registers: all but this wave's 16 tile-out stores are done ----
+    if (DEBUG || first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    first = false;
+#pragma unroll
+    for (int i = 0; i < MAX_TILE_ITERS; ++i) asm volatile("" : "+v"(v[i]));
+    asm volatile("" : "+v"(mp[0]), "+v"(mp[1]));
+    // ---- registers -> LDS: the tile (head CNOTs of the pass folded into the slot) and the matrices ----
+    if (init) {
+      for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
+    } else if (!(dbg & 4)) {
+      const uint32_t slot_t = slot_in ^ xor_map16(g, gbits, in_gmask);
+#pragma unroll
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+        const uint32_t its = ((i & 1) ? imask[0] : 0u) ^ ((i & 2) ? imask[1] : 0u) ^ ((i & 4) ? imask[2] : 0u) ^ ((i & 8) ? imask[3] : 0u);
+        tile[slot_t ^ its] = make_double2(v[i].x, v[i].y);
+      }
+    }
+    if (mat_off[0] >= 0) mats[t] = make_double2(mp[0].x, mp[0].y);
+    if (mat_off[1] >= 0) mats[t + T] = make_double2(mp[1].x, mp[1].y);
+    asm volatile("" ::: "memory");   // the registers are free: LDS writes above, next tile's loads below
+    // ---- the next tile starts its trip from HBM now ----
+    if (Tcur + gridDim.x < total_tiles) BORNVI_PREFETCH(Tcur + gridDim.x);
+    __syncthreads();
+
+    // ---- stages ----
+    const uint32_t* __restrict__ FS = F + FH_WORDS;
+    for (int s = 0; s < nstages; ++s, FS += FS_WORDS) {
+      uint32_t G[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) G[i] = FS[i];
+      const uint32_t kind = FS[FS_KIND];
+      const uint32_t my_rw = tab_rw[(uint32_t)s * T + t];
+      const uint32_t my_sg = (kind >> 3) ? tab_sg[(uint32_t)s * T + t] : 0u;
+      const double2* __restrict__ Us = mats + s * 16;
+      // stage kind: number of fused gates (on register bits 0 .. ng-1) | pre sign << 3 | post sign << 4
+#define BORNVI_STAGE(NG, PRE, POST) \
+  case (NG) | ((PRE) << 3) | ((POST) << 4): stage_body<NG, PRE, POST, DEBUG>(tile, Us, my_rw, my_sg, G, dbg); break;
+#define BORNVI_STAGE_NG(PRE, POST) \
+  BORNVI_STAGE(0, PRE, POST) BORNVI_STAGE(1, PRE, POST) BORNVI_STAGE(2, PRE, POST) BORNVI_STAGE(3, PRE, POST) BORNVI_STAGE(4, PRE, POST)
+      switch (kind) {
+        BORNVI_STAGE_NG(0, 0)
+        BORNVI_STAGE_NG(1, 0)
+        BORNVI_STAGE_NG(0, 1)
+        BORNVI_STAGE_NG(1, 1)
+        default: break;
+      }
+#undef BORNVI_STAGE_NG
+#undef BORNVI_STAGE
+      __syncthreads();
+    }
+
+    // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
+    // vector-memory stores per wave (the vmcnt(16) above counts them) ----
+    {
+      const uint32_t gout = deposit16(g, 0, gbits, out_gphys);
+      const uint32_t thr_l = slot_out ^ xor_map16(g, gbits, out_gmask);   // tail CNOTs folded in
+      double2* dst = out + b * state_stride + gout;
+      double* pdst = probs + (b << n) + gout;
+#pragma unroll
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+        const uint32_t it_l = ((i & 1) ? lpos[0] : 0u) ^ ((i & 2) ? lpos[1] : 0u) ^ ((i & 4) ? lpos[2] : 0u) ^ ((i & 8) ? lpos[3] : 0u);
+        const uint32_t it_p = ((i & 1) ? 1u << ppos[0] : 0u) | ((i & 2) ? 1u << ppos[1] : 0u) |
+                              ((i & 4) ? 1u << ppos[2] : 0u) | ((i & 8) ? 1u << ppos[3] : 0u);
+        const double2 x = tile[thr_l ^ it_l];
+        if (DEBUG && (dbg & 8)) continue;
+        if (fin) async_store8(thr_out | (it_p << 3), x.x * x.x + x.y * x.y, pdst);
+        else async_store16(thr_out | (it_p << 4), (d2_t){x.x, x.y}, dst);
+      }
+    }
+    __syncthreads();   // the tile and the matrices are overwritten by the next tile
+  }
+#undef BORNVI_PREFETCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,10 +809,12 @@ hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* th
 }
 
 hipError_t prepare_circuit_kernel(size_t lds_bytes) {
-  const void* fns[4] = {reinterpret_cast<const void*>(circuit_pass_kernel<true, false>),
+  const void* fns[6] = {reinterpret_cast<const void*>(circuit_pass_kernel<true, false>),
                         reinterpret_cast<const void*>(circuit_pass_kernel<false, false>),
                         reinterpret_cast<const void*>(circuit_pass_kernel<true, true>),
-                        reinterpret_cast<const void*>(circuit_pass_kernel<false, true>)};
+                        reinterpret_cast<const void*>(circuit_pass_kernel<false, true>),
+                        reinterpret_cast<const void*>(circuit_pass_fast_kernel<false>),
+                        reinterpret_cast<const void*>(circuit_pass_fast_kernel<true>)};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -500,16 +822,47 @@ hipError_t prepare_circuit_kernel(size_t lds_bytes) {
   return hipSuccess;
 }
 
+int circuit_fast_workgroups_per_cu(int threads, size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_fast_kernel<false>, threads, lds) != hipSuccess) return 0;
+  return nb;
+}
+
+hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, const uint32_t* fast, uint32_t fast_off,
+                                    int n, int k, size_t lds, int batch, const void* in, void* out, double* probs,
+                                    const double* gates, long long gate_stride, int max_workgroups, size_t lds_tab_off,
+                                    int dbg, hipStream_t st) {
+  const long long total_tiles = (long long)batch << (n - k);
+  if (total_tiles == 0) return hipSuccess;
+  long long wgs = (max_workgroups > 0 && total_tiles > max_workgroups) ? max_workgroups : total_tiles;
+  // a grid that is a multiple of the tiles per state keeps every workgroup on one tile row (its stage tables
+  // stay in LDS for the whole launch)
+  const long long per_state = 1ll << (n - k);
+  if (wgs > per_state) wgs -= wgs % per_state;
+  dim3 grid((unsigned)wgs);
+  const dim3 block(1u << (k - 4));
+  if (!dbg)
+    circuit_pass_fast_kernel<false><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
+                                                            probs, gates, gate_stride, 1ll << n, total_tiles,
+                                                            (uint32_t)(lds_tab_off / 16), 0);
+  else
+    circuit_pass_fast_kernel<true><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
+                                                           probs, gates, gate_stride, 1ll << n, total_tiles,
+                                                           (uint32_t)(lds_tab_off / 16), dbg);
+  return hipGetLastError();
+}
+
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,
                                const void* in, void* out, double* probs, const double* gates,
-                               long long gate_stride, int dbg, hipStream_t st) {
-  dim3 grid(1u << (n - k), (unsigned)batch);
+                               long long gate_stride, int max_workgroups, int dbg, hipStream_t st) {
+  const long long total_tiles = (long long)batch << (n - k);
+  dim3 grid((unsigned)((max_workgroups > 0 && total_tiles > max_workgroups) ? max_workgroups : total_tiles));
   int tau = 0;
   while ((1 << tau) < threads) ++tau;
   const bool full = (k - tau) == 4;   // 16 tile elements per thread
 #define BORNVI_LAUNCH_PASS(F, D)                                                     \
   circuit_pass_kernel<F, D><<<grid, dim3(threads), lds, st>>>(                       \
-      plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, dbg)
+      plan, pass_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles, dbg)
   if (full && !dbg) BORNVI_LAUNCH_PASS(true, false);
   else if (full) BORNVI_LAUNCH_PASS(true, true);
   else if (!dbg) BORNVI_LAUNCH_PASS(false, false);

@@ -510,7 +510,13 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       if (sel.count() == 0) { msg = "stage planner made no progress"; return false; }
       // register wires: targets, padded with local wires (highest LDS bits first)
       std::vector<char> isr(n, 0);
-      std::vector<int> regw = sel.targets;
+      std::vector<int> regw;   // wires carrying a fused U first (the fast kernel's stage kinds count them)
+      {
+        std::vector<char> has_u(n, 0);
+        for (int idx : sel.us) has_u[ops[idx].a] = 1;
+        for (int w : sel.targets) if (has_u[w]) regw.push_back(w);
+        for (int w : sel.targets) if (!has_u[w]) regw.push_back(w);
+      }
       for (int w : regw) isr[w] = 1;
       for (int j = k - 1; j >= 0 && (int)regw.size() < r; --j)
         if (!isr[P.lds_wire[j]]) { isr[P.lds_wire[j]] = 1; regw.push_back(P.lds_wire[j]); }
@@ -605,5 +611,105 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
   return true;
 }
 }  // namespace
+
+// ---- fast-path tables ---------------------------------------------------------------------------
+// Evaluates, per (stage, tile, thread), exactly what circuit_pass_kernel computes at run time from the
+// stage header (see also tests/plan_emulator.py, which interprets the same words).
+bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
+  out.words.clear(); out.pass_off.clear(); out.any_sign = false;
+  const int n = plan.n, k = plan.k;
+  if (plan.r != 4 || k < 10 || plan.threads != (1 << (k - 4)) || n - k > 16) return false;
+  const int kt = k - 4;
+  const size_t per_stage = (size_t)1 << (n - 4);
+  size_t total = 0;
+  for (int i = 0; i < plan.n_passes; ++i) {
+    const uint32_t* P = plan.words.data() + plan.pass_off[i];
+    const uint32_t nst = P[PW_NSTAGES];
+    if (nst > (uint32_t)MAX_STAGES || nst * 16u > 2u * (uint32_t)plan.threads) return false;
+    bool any_sign = false;
+    const uint32_t* S = P + PW_STAGES;
+    for (uint32_t s = 0; s < nst; ++s) { if ((S[0] >> 8) & 0xffu) any_sign = true; S += S[0] >> 16; }
+    total += FH_WORDS + (size_t)nst * FS_WORDS + (size_t)nst * per_stage * (any_sign ? 2 : 1);
+  }
+  if (total * sizeof(uint32_t) > max_bytes || total >= (size_t)0xffffffffu) return false;
+  std::vector<uint32_t>& W = out.words;
+  W.reserve(total);
+  auto parity = [](uint32_t v) { return (uint32_t)__builtin_popcount(v) & 1u; };
+  for (int i = 0; i < plan.n_passes; ++i) {
+    const uint32_t* P = plan.words.data() + plan.pass_off[i];
+    const uint32_t nst = P[PW_NSTAGES];
+    const uint32_t hbase = (uint32_t)W.size();
+    out.pass_off.push_back(hbase);
+    W.resize(hbase + FH_WORDS + (size_t)nst * FS_WORDS, 0);
+    uint32_t sign_pre = 0, sign_post = 0;
+    {
+      const uint32_t* S = P + PW_STAGES;
+      for (uint32_t s = 0; s < nst; ++s) {
+        const uint32_t sf = (S[0] >> 8) & 0xffu;
+        if (sf & STAGE_SIGN_PRE) sign_pre |= 1u << s;
+        if (sf & STAGE_SIGN_POST) sign_post |= 1u << s;
+        S += S[0] >> 16;
+      }
+    }
+    const bool any_sign = (sign_pre | sign_post) != 0;
+    if (any_sign) out.any_sign = true;
+    const uint32_t rw_base = (uint32_t)W.size();
+    W.resize(W.size() + (size_t)nst * per_stage, 0);
+    const uint32_t sg_base = any_sign ? (uint32_t)W.size() : 0u;
+    if (any_sign) W.resize(W.size() + (size_t)nst * per_stage, 0);
+    W[hbase + FH_NSTAGES] = nst; W[hbase + FH_RW_BASE] = rw_base; W[hbase + FH_SG_BASE] = sg_base;
+    W[hbase + FH_SIGN_PRE] = sign_pre; W[hbase + FH_SIGN_POST] = sign_post;
+    const uint32_t* S = P + PW_STAGES;
+    for (uint32_t s = 0; s < nst; ++s) {
+      const uint32_t hdr = S[0];
+      if ((hdr & 0xffu) != 4u) { out.words.clear(); out.pass_off.clear(); return false; }
+      const uint32_t sflags = (hdr >> 8) & 0xffu, nwords = hdr >> 16, rho = S[1];
+      uint32_t* FS = W.data() + hbase + FH_WORDS + (size_t)s * FS_WORDS;
+      FS[FS_FI01] = S[6]; FS[FS_FI23] = S[7];
+      {   // gates must occupy register bits 0 .. ng-1 (stage planner: U-carrying wires first)
+        const uint32_t fi[4] = {S[6] & 0xffffu, S[6] >> 16, S[7] & 0xffffu, S[7] >> 16};
+        uint32_t ng = 0;
+        while (ng < 4 && fi[ng] != 0xffffu) ++ng;
+        for (uint32_t b = ng; b < 4; ++b)
+          if (fi[b] != 0xffffu) { out.words.clear(); out.pass_off.clear(); return false; }
+        FS[FS_KIND] = ng | ((sflags & STAGE_SIGN_PRE) ? 8u : 0u) | ((sflags & STAGE_SIGN_POST) ? 16u : 0u);
+      }
+      for (int b = 0; b < 4; ++b) { FS[FS_RB + b] = S[16 + (1 << b)] << 4; FS[FS_WB + b] = S[32 + (1 << b)] << 4; }
+      for (int j = 0; j < 16; ++j) {   // the slot offsets must be linear in the slot number
+        uint32_t lr = 0, lw = 0;
+        for (int b = 0; b < 4; ++b) if (j >> b & 1) { lr ^= S[16 + (1 << b)]; lw ^= S[32 + (1 << b)]; }
+        if (lr != S[16 + j] || lw != S[32 + j]) { out.words.clear(); out.pass_off.clear(); return false; }
+      }
+      uint32_t sri[4], rpos[4];
+      for (int b = 0; b < 4; ++b) { rpos[b] = (rho >> (8 * b)) & 0xffu; sri[b] = lds_swizzle(1u << rpos[b]); }
+      const uint32_t* Qpre = (sflags & STAGE_SIGN_PRE) ? S + STAGE_HDR_WORDS : nullptr;
+      const uint32_t* Qpost = (sflags & STAGE_SIGN_POST) ? S + STAGE_HDR_WORDS + (Qpre ? SIGNQ_WORDS : 0) : nullptr;
+      const uint32_t* tab = S + STAGE_HDR_WORDS + (Qpre ? SIGNQ_WORDS : 0) + (Qpost ? SIGNQ_WORDS : 0);
+      auto sign_bits = [&](const uint32_t* Q, uint32_t e) {
+        uint32_t acc = 0;
+        for (int q = 0; q < n; ++q) acc ^= ((e >> q) & 1u) & parity(e & Q[q]);
+        uint32_t m = 0;
+        for (int j = 0; j < 16; ++j) m |= (((Q[48] >> j) ^ acc ^ parity(e & Q[32 + j])) & 1u) << j;
+        return m;
+      };
+      uint32_t* RW = W.data() + rw_base + (size_t)s * per_stage;
+      uint32_t* SG = any_sign ? W.data() + sg_base + (size_t)s * per_stage : nullptr;
+      for (uint32_t g = 0; g < (1u << (n - k)); ++g)
+        for (uint32_t t = 0; t < (1u << kt); ++t) {
+          const uint32_t pb = tab[t] & 0xffffu, base = tab[t] >> 16;
+          const uint32_t e = base | (g << k);
+          uint32_t lflip = 0, sflip = 0, e2 = e;
+          for (int b = 0; b < 4; ++b) {
+            if (parity(e & S[8 + b])) lflip ^= sri[b];
+            if (parity(e & S[12 + b])) { sflip ^= sri[b]; e2 |= 1u << rpos[b]; }
+          }
+          RW[((size_t)g << kt) + t] = (pb ^ lflip) | ((pb ^ sflip) << 16);
+          if (SG) SG[((size_t)g << kt) + t] = (Qpre ? sign_bits(Qpre, e) : 0u) | ((Qpost ? sign_bits(Qpost, e2) : 0u) << 16);
+        }
+      S += nwords;
+    }
+  }
+  return true;
+}
 
 }  // namespace bornvi

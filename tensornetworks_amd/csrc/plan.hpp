@@ -125,7 +125,39 @@ struct Plan {
   std::vector<uint32_t> pass_off;  // word offset of each pass descriptor
   // tile + the matrices of the longest pass, rounded up to 512 bytes
   size_t lds_bytes() const { return (size_t(1) << k) * 16 + (((size_t)(max_stages > 0 ? max_stages : 1) * STAGE_MATS_BYTES + 511) / 512) * 512; }
+  // fast kernel: the above, then one tile row of the RW (and SG) stage tables of the longest pass
+  size_t fast_lds_tab_off() const { return lds_bytes(); }
+  size_t fast_lds_bytes(bool any_sign) const {
+    return lds_bytes() + (size_t)(max_stages > 0 ? max_stages : 1) * ((size_t)1 << (k - 4)) * 4 * (any_sign ? 2 : 1);
+  }
 };
+
+// ---- fast-path tables (kernels_circuit.hip: circuit_pass_fast_kernel) ---------------------------
+// Derived from the serialised plan above (same semantics, evaluated once on the host): for every stage of
+// every pass and every (tile g, thread t) the swizzled LDS slot the thread's 16-amplitude group is read from /
+// written to with ALL index-dependent CNOT flips folded in, and -- for stages carrying CZ products -- the
+// 16 sign bits of its slots.  The kernel then does no index arithmetic per stage beyond one table load.
+// Layout of `words` (uint32):
+//   pass header, FH_WORDS words:  [FH_NSTAGES] [FH_RW_BASE] [FH_SG_BASE] [FH_SIGN_PRE] [FH_SIGN_POST]
+//       RW_BASE / SG_BASE: word offsets (from the start of `words`) of the tables of stage 0; stage s is
+//       2^(n-4) words further per stage; SIGN_PRE / SIGN_POST: bit s set = stage s applies that sign
+//   stage header s at  pass header + FH_WORDS + s * FS_WORDS:
+//       [FS_FI01] [FS_FI23] fused gate of register bit i (16 bits each, 0xffff = none)
+//       [FS_KIND] number of fused gates (they sit on register bits 0 .. ng-1) | pre sign << 3 | post sign << 4
+//       [FS_RB .. +3] byte offset xor-ed into the LDS READ address for register bit i of the slot number
+//       [FS_WB .. +3] same for the WRITE address   (slot offsets are GF(2)-linear in the slot number)
+//   tables: RW[s][g][t] = read slot | write slot << 16;  SG[s][g][t] = pre signs | post signs << 16
+enum FastHeader : int { FH_NSTAGES = 0, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_WORDS = 8 };
+enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10, FS_WORDS = 16 };
+
+struct FastTables {
+  std::vector<uint32_t> words;
+  std::vector<uint32_t> pass_off;   // word offset of each pass's header
+  bool any_sign = false;            // some stage carries a CZ sign product (the SG tables exist)
+};
+// false (tables empty) when the plan is not eligible: tiles smaller than 2^10, more stage matrices than two
+// per thread, or tables above `max_bytes`; the generic kernel then runs the plan.
+bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out);
 
 // Returns false (with msg) on unsupported sizes.
 bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& out, std::string& msg);

@@ -20,6 +20,9 @@ STAGE_HDR_WORDS = 48
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
 SIGNQ_WORDS = 49
 KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
+# fast-path tables (plan.hpp: FastHeader / FastStage)
+FH_NSTAGES, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_WORDS = 0, 1, 2, 3, 4, 8
+FS_FI01, FS_FI23, FS_RB, FS_WB, FS_KIND, FS_WORDS = 0, 1, 2, 6, 10, 16
 
 
 def fused_matrices(W, theta):
@@ -79,8 +82,60 @@ def popc(x):
     return c
 
 
-def run_plan(W, mats, state_in=None):
-    """Returns probabilities (PASS_FINAL) or the final state (PASS_FINAL_STATE), canonical order."""
+def fast_stage(F, FH, s, g, k, n, tile, mats):
+    """One stage exactly as circuit_pass_fast_kernel runs it: slots and signs from the planner tables."""
+    kt = k - 4
+    nthr = 1 << kt
+    FS = FH + FH_WORDS + s * FS_WORDS
+    per_stage = 1 << (n - 4)
+    rw = F[int(F[FH + FH_RW_BASE]) + s * per_stage + (g << kt): int(F[FH + FH_RW_BASE]) + s * per_stage + (g << kt) + nthr].astype(np.int64)
+    pre = (int(F[FH + FH_SIGN_PRE]) >> s) & 1
+    post = (int(F[FH + FH_SIGN_POST]) >> s) & 1
+    kind = int(F[FS + FS_KIND])
+    assert ((kind >> 3) & 1) == pre and ((kind >> 4) & 1) == post
+    ng = kind & 7
+    fi = [int(F[FS + FS_FI01]) & 0xFFFF, int(F[FS + FS_FI01]) >> 16, int(F[FS + FS_FI23]) & 0xFFFF, int(F[FS + FS_FI23]) >> 16]
+    assert all(f != 0xFFFF for f in fi[:ng]) and all(f == 0xFFFF for f in fi[ng:])
+    rb = [int(F[FS + FS_RB + b]) for b in range(4)]
+    wb = [int(F[FS + FS_WB + b]) for b in range(4)]
+
+    def addr(base_slot, basis, j):
+        a = base_slot << 4
+        for b in range(4):
+            if (j >> b) & 1:
+                a = a ^ basis[b]
+        assert np.all(a % 16 == 0)
+        return swz_inv(a >> 4)
+    rd = [addr(rw & 0xFFFF, rb, j) for j in range(16)]
+    wr = [addr(rw >> 16, wb, j) for j in range(16)]
+    assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(1 << k))
+    assert np.array_equal(np.sort(np.concatenate(wr)), np.arange(1 << k))
+    assert np.array_equal(np.sort(np.stack(rd), axis=0), np.sort(np.stack(wr), axis=0))   # a thread's own group
+    amp = [tile[rd[j]].copy() for j in range(16)]
+    if pre or post:
+        sgw = F[int(F[FH + FH_SG_BASE]) + s * per_stage + (g << kt): int(F[FH + FH_SG_BASE]) + s * per_stage + (g << kt) + nthr].astype(np.int64)
+    if pre:
+        for j in range(16):
+            amp[j] = np.where(((sgw >> j) & 1).astype(bool), -amp[j], amp[j])
+    for a in range(ng):
+        U = mats[fi[a]]
+        for j in range(16):
+            if j & (1 << a):
+                continue
+            j1 = j | (1 << a)
+            x0, x1 = amp[j], amp[j1]
+            amp[j], amp[j1] = U[0, 0] * x0 + U[0, 1] * x1, U[1, 0] * x0 + U[1, 1] * x1
+    if post:
+        for j in range(16):
+            amp[j] = np.where(((sgw >> (16 + j)) & 1).astype(bool), -amp[j], amp[j])
+    for j in range(16):
+        tile[wr[j]] = amp[j]
+
+
+def run_plan(W, mats, state_in=None, fast=None):
+    """Returns probabilities (PASS_FINAL) or the final state (PASS_FINAL_STATE), canonical order.
+    fast = (words, pass offsets) of the fast-path tables: the stages are then taken from those tables (as
+    circuit_pass_fast_kernel does) instead of the stage headers (as circuit_pass_kernel does)."""
     W = np.asarray(W, dtype=np.uint32)
     n, k, np_ = int(W[PH_N]), int(W[PH_K]), int(W[PH_NPASSES])
     N = 1 << n
@@ -118,7 +173,13 @@ def run_plan(W, mats, state_in=None):
                 tile = np.zeros(ksize, dtype=np.complex128)
                 tile[slot] = buf[phys]
             S = P[PW_STAGES:]
-            for si in range(nst):
+            if fast is not None:
+                Fw, Foffs = fast
+                FH = int(Foffs[pi])
+                assert int(Fw[FH + FH_NSTAGES]) == nst
+                for si in range(nst):
+                    fast_stage(Fw, FH, si, g, k, n, tile, mats)
+            for si in range(nst if fast is None else 0):
                 # the per-pass matrix table (what the kernel stages into LDS) must agree with the stage header
                 assert int(P[PW_MATS + 2 * si]) == int(S[6]) and int(P[PW_MATS + 2 * si + 1]) == int(S[7])
                 hdr = int(S[0]); r = hdr & 0xFF; sflags = (hdr >> 8) & 0xFF; nwords = hdr >> 16

@@ -59,6 +59,42 @@ def test_planner_against_oracle(ansatz, n, L, kb):
     assert st["gates"] == len(oc.gate_list(ansatz, n, L)) and st["k"] == min(n, kb or 13)
 
 
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb", [(10, 2, 0), (11, 2, 10), (12, 3, 0), (13, 2, 11), (13, 1, 13), (14, 2, 12)])
+def test_fast_tables_against_oracle(ansatz, n, L, kb):
+    """The per-(stage, tile, thread) tables the fast pass kernel reads (LDS slots with the CNOT index maps
+    folded in, CZ sign bits, slot-offset bases, stage kinds), interpreted as that kernel interprets them."""
+    from tensornetworks_amd import _ext
+    aid = _ext.ANSATZ_IDS[ansatz]
+    W = _ext.plan_words(aid, n, L, kb)
+    F, offs = _ext.plan_fast_words(aid, n, L, kb)
+    assert F is not None, "plan should be eligible for the fast kernel"
+    th = np.random.default_rng(n * 7 + L).uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
+    q = pe.run_plan(W, pe.fused_matrices(W, th), fast=(F, offs))
+    np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
+
+
+def test_fast_tables_eligibility_and_kron():
+    from tensornetworks_amd import _ext
+    assert _ext.plan_fast_words(0, 8, 4, 0) == (None, None)          # tiles below 2^10: generic kernel
+    assert _ext.plan_fast_words(0, 12, 2, 8) == (None, None)
+    for n, L in [(16, 6), (20, 8)]:
+        F, offs = _ext.plan_fast_words(0, n, L, 0)
+        W = _ext.plan_words(0, n, L, 0)
+        assert F is not None and len(offs) == int(W[3]) and len(F) * 4 < 64 << 20
+    n, kb = 12, 10
+    W = _ext.plan_words(-1, n, 0, kb)
+    F, offs = _ext.plan_fast_words(-1, n, 0, kb)
+    assert F is not None
+    a = np.exp(-1.0 / n)
+    M = np.array([[1, a], [a, 1]], dtype=np.complex128)
+    rng = np.random.default_rng(n)
+    v = rng.normal(size=2 ** n) + 1j * rng.normal(size=2 ** n)
+    out = pe.run_plan(W, [M], state_in=v, fast=(F, offs))
+    ref = os_.kbase_apply(v.real, n, a) + 1j * os_.kbase_apply(v.imag, n, a)
+    np.testing.assert_allclose(out, ref, rtol=1e-13, atol=1e-13)
+
+
 @pytest.mark.parametrize("n,kb", [(1, 0), (3, 0), (6, 4), (9, 5), (10, 7), (12, 13)])
 def test_kron_plan_against_oracle(n, kb):
     """State-in / state-out program for K_base = M^{(x) n} (matrix-free Stein mat-vec)."""
