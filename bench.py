@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--wgs-per-cu", type=int, default=-1, help="generic circuit kernel: persistent workgroups per CU (0 = one per tile)")
     ap.add_argument("--fast-path", type=int, default=-1, help="0: force the generic circuit kernel (A/B against the fast one)")
     ap.add_argument("--fast-wgs-per-cu", type=int, default=-1, help="fast circuit kernel: persistent workgroups per CU (0 = occupancy query)")
+    ap.add_argument("--opt", action="append", default=[], help="backend option name=value (e.g. low_bits=7), repeatable")
     ap.add_argument("--overlap", type=int, default=-1, help="1/0: contraction on a second stream beside the shifted circuits")
     args = ap.parse_args()
 
@@ -150,6 +151,9 @@ def main():
         backend.set_option(dev, "tile_bits", args.tile_bits)
     if args.debug_flags:
         backend.set_option(dev, "debug_flags", args.debug_flags)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        backend.set_option(dev, name, int(val))
     if args.wgs_per_cu >= 0:
         backend.set_option(dev, "workgroups_per_cu", args.wgs_per_cu)
     if args.fast_path >= 0:

@@ -225,7 +225,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;
   else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
   else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
-  if (o.kmax < 4 || o.kmax > 13 || o.kmulti < 4 || o.kmulti > 13 || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
+  if (o.kmax < 4 || o.kmax > 13 || (o.kmulti != 0 && (o.kmulti < 4 || o.kmulti > 13)) || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
       (o.max_threads & (o.max_threads - 1)))
     return fail(h, BORNVI_ERR_INVALID, "option value out of range");
   h->opt = o;

@@ -154,6 +154,15 @@ __device__ __forceinline__ uint32_t xor_map16(uint32_t v, int nbits, const uint3
   return o;
 }
 
+// xor over bits j in [0, nbits) of v of cols[j] (32-bit columns in the plan: GF(2)-linear phys-out address)
+__device__ __forceinline__ uint32_t xor_cols(uint32_t v, int nbits, const uint32_t* __restrict__ cols) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nbits) o ^= (0u - ((v >> j) & 1u)) & cols[j];
+  return o;
+}
+
 // table entry at a run-time (wave-uniform) index
 __device__ __forceinline__ uint32_t half16_dyn(const uint32_t (&w)[8], int idx) {
   uint32_t o = 0;
@@ -344,25 +353,25 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
 
   // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order ---------------
   if (t < ksize && !(dbg & 8)) {
-    const uint32_t gout = deposit16(g, 0, n - k, out_gphys);
+    // phys-out address: GF(2)-linear in the out-enumeration index and the tile index (plan.hpp: PW_OUT_COL)
+    const uint32_t gout = xor_cols(g, n - k, P + PW_OUT_GCOL);
     const uint32_t thr_l = xor_map16(t, kt, out_mask) ^ xor_map16(g, n - k, out_gmask);   // tail CNOTs folded in
-    const uint32_t thr_p = (t & ((1u << lo_out) - 1u)) | deposit16(t, lo_out, kt, out_phys);
-    uint32_t lpos[4], ppos[4];
+    const uint32_t thr_p = xor_cols(t, kt, P + PW_OUT_COL) ^ gout;
+    uint32_t lpos[4], pcol[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       lpos[m] = (kt + m < k) ? half16_dyn(out_mask, kt + m) : 0u;
-      ppos[m] = (kt + m < k) ? byte16(out_phys, (uint32_t)(kt + m)) : 0u;
+      pcol[m] = (kt + m < k) ? P[PW_OUT_COL + kt + m] : 0u;
     }
     const bool fin = flags & PASS_FINAL;
-    double2* __restrict__ dst = out + b * state_stride + gout;
-    double* __restrict__ pdst = probs + (b << n) + gout;
+    double2* __restrict__ dst = out + b * state_stride;
+    double* __restrict__ pdst = probs + (b << n);
     auto move_out = [&](int i) {
       const uint32_t it_l = ((i & 1) ? lpos[0] : 0u) ^ ((i & 2) ? lpos[1] : 0u) ^ ((i & 4) ? lpos[2] : 0u) ^ ((i & 8) ? lpos[3] : 0u);
-      const uint32_t it_p = ((i & 1) ? 1u << ppos[0] : 0u) | ((i & 2) ? 1u << ppos[1] : 0u) |
-                            ((i & 4) ? 1u << ppos[2] : 0u) | ((i & 8) ? 1u << ppos[3] : 0u);
+      const uint32_t it_p = ((i & 1) ? pcol[0] : 0u) ^ ((i & 2) ? pcol[1] : 0u) ^ ((i & 4) ? pcol[2] : 0u) ^ ((i & 8) ? pcol[3] : 0u);
       const double2 v = tile[thr_l ^ it_l];
-      if (fin) pdst[thr_p | it_p] = v.x * v.x + v.y * v.y;
-      else dst[thr_p | it_p] = v;
+      if (fin) pdst[thr_p ^ it_p] = v.x * v.x + v.y * v.y;
+      else dst[thr_p ^ it_p] = v;
     };
     if (FULL) {
 #pragma unroll
@@ -548,14 +557,15 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
   const uint32_t thr_in = ((t & ((1u << lo_in) - 1u)) | deposit16(t, lo_in, kt, in_phys)) << 4;      // bytes
   const uint32_t slot_in = xor_map16(t, kt, in_mask);
   const uint32_t slot_out = xor_map16(t, kt, out_mask);
-  const uint32_t thr_out = ((t & ((1u << lo_out) - 1u)) | deposit16(t, lo_out, kt, out_phys)) << (fin ? 3 : 4);
-  uint32_t ipos[4], imask[4], lpos[4], ppos[4];
+  const int out_shift = fin ? 3 : 4;   // bytes per element written
+  const uint32_t thr_out = xor_cols(t, kt, P + PW_OUT_COL) << out_shift;   // phys-out address: GF(2)-linear (PW_OUT_COL)
+  uint32_t ipos[4], imask[4], lpos[4], pcol[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     ipos[m] = byte16(in_phys, (uint32_t)(kt + m));
     imask[m] = half16_dyn(in_mask, kt + m);
     lpos[m] = half16_dyn(out_mask, kt + m);
-    ppos[m] = byte16(out_phys, (uint32_t)(kt + m));
+    pcol[m] = P[PW_OUT_COL + kt + m] << out_shift;
   }
   // the (at most two) 16-byte pieces of the pass's matrices this thread stages per tile
   int mat_off[2];
@@ -666,19 +676,18 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
     // vector-memory stores per wave (the vmcnt(16) above counts them) ----
     {
-      const uint32_t gout = deposit16(g, 0, gbits, out_gphys);
+      const uint32_t gout = xor_cols(g, gbits, P + PW_OUT_GCOL) << out_shift;
       const uint32_t thr_l = slot_out ^ xor_map16(g, gbits, out_gmask);   // tail CNOTs folded in
-      double2* dst = out + b * state_stride + gout;
-      double* pdst = probs + (b << n) + gout;
+      double2* dst = out + b * state_stride;
+      double* pdst = probs + (b << n);
 #pragma unroll
       for (int i = 0; i < MAX_TILE_ITERS; ++i) {
         const uint32_t it_l = ((i & 1) ? lpos[0] : 0u) ^ ((i & 2) ? lpos[1] : 0u) ^ ((i & 4) ? lpos[2] : 0u) ^ ((i & 8) ? lpos[3] : 0u);
-        const uint32_t it_p = ((i & 1) ? 1u << ppos[0] : 0u) | ((i & 2) ? 1u << ppos[1] : 0u) |
-                              ((i & 4) ? 1u << ppos[2] : 0u) | ((i & 8) ? 1u << ppos[3] : 0u);
+        const uint32_t it_p = gout ^ ((i & 1) ? pcol[0] : 0u) ^ ((i & 2) ? pcol[1] : 0u) ^ ((i & 4) ? pcol[2] : 0u) ^ ((i & 8) ? pcol[3] : 0u);
         const double2 x = tile[thr_l ^ it_l];
         if (DEBUG && (dbg & 8)) continue;
-        if (fin) async_store8(thr_out | (it_p << 3), x.x * x.x + x.y * x.y, pdst);
-        else async_store16(thr_out | (it_p << 4), (d2_t){x.x, x.y}, dst);
+        if (fin) async_store8(thr_out ^ it_p, x.x * x.x + x.y * x.y, pdst);
+        else async_store16(thr_out ^ it_p, (d2_t){x.x, x.y}, dst);
       }
     }
     __syncthreads();   // the tile and the matrices are overwritten by the next tile

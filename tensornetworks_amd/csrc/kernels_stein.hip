@@ -5,6 +5,7 @@
 //
 // Index convention: outcome index i <-> tuple z with z[b] = (i >> (n-1-b)) & 1 (utils.py:77-91).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 
@@ -293,9 +294,12 @@ __device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
 }
 
 // one strip: rows [s SYM_ROWS, (s+1) SYM_ROWS), columns >= s SYM_ROWS
+// `half` (0 / 1): the strip's column range is cut in two (at a multiple of 128) and each half is its own work
+// item with its own row partials, so that twice as many waves stream (two per SIMD hide each other's
+// load-batch latency: one wave per SIMD left HBM idle while it ran its FMAs)
 __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ K, const double* __restrict__ q,
                                                    double* __restrict__ yrow, double* __restrict__ Z, long long N,
-                                                   long long s, int lane) {
+                                                   long long s, int lane, int half) {
   const long long i0 = s * SYM_ROWS;
   const int nrows = (int)((N - i0 < SYM_ROWS) ? N - i0 : SYM_ROWS);
   double qi[SYM_ROWS];
@@ -306,8 +310,83 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ K,
   for (int r = 0; r < SYM_ROWS; ++r) acc[r] = 0.0;
   double* __restrict__ Zs = Z + sym_z_offset(s, N) - (i0 + SYM_ROWS);   // so that Zs[j] is the entry of column j
   const double* __restrict__ Kr = K + i0 * N;
+  const long long cstart = (i0 / 128) * 128;
+  const long long cmid = cstart + ((N - cstart) / 256) * 128;
+  const long long cbeg = half ? cmid : cstart, cend = half ? N : cmid;
+  // main loop: 512 columns per trip = 4 KiB contiguous per row (8 rows x 4 chunks = 32 loads in flight; with
+  // 1 KiB per row and 32 rows in flight every load of a batch opened a different DRAM page 512 KiB apart)
+  long long c = cbeg + lane * 2;
+  const long long first_full = ((i0 + SYM_ROWS + 127) / 128) * 128;   // from here on every column is off-diagonal
+  if (nrows == SYM_ROWS) {
+    // triangle / diagonal chunks first with the general loop below, then the wide loop
+    long long cw = cbeg > first_full ? cbeg : first_full;
+    if (cw > cend) cw = cend;
+    const long long wide_end = cw + ((cend - cw) / 512) * 512;
+    // general loop over [cbeg, cw) happens below via `c`; the wide part [cw, wide_end) here
 #pragma unroll 1
-  for (long long c = (i0 / 128) * 128 + lane * 2; c < N; c += 128) {
+    for (long long cb = cw; cb < wide_end; cb += 512) {
+      double2 q4[4];
+      double z[4][2];
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        q4[u4] = *reinterpret_cast<const double2*>(q + cb + u4 * 128 + lane * 2);
+        z[u4][0] = 0.0; z[u4][1] = 0.0;
+      }
+#pragma unroll
+      for (int r0 = 0; r0 < SYM_ROWS; r0 += 8) {
+        double2 kv[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) {
+            const double* p = Kr + (long long)(r0 + u) * N + cb + u4 * 128 + lane * 2;
+            kv[u][u4].x = __builtin_nontemporal_load(p); kv[u][u4].y = __builtin_nontemporal_load(p + 1);
+          }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) {
+            acc[r0 + u] = fma(kv[u][u4].x, q4[u4].x, fma(kv[u][u4].y, q4[u4].y, acc[r0 + u]));
+            z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
+            z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
+          }
+      }
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4)
+        *reinterpret_cast<double2*>(Zs + cb + u4 * 128 + lane * 2) = make_double2(z[u4][0], z[u4][1]);
+    }
+    // the general loop covers [cbeg, cw) and then [wide_end, cend)
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+      const long long pb = part ? wide_end : cbeg, pe = part ? cend : cw;
+      for (long long cc = pb + lane * 2; cc < pe; cc += 128) {
+        const bool in_tri = cc >= i0;
+        const bool off_diag = cc >= i0 + SYM_ROWS;
+        if (!in_tri) continue;
+        const double2 q2 = *reinterpret_cast<const double2*>(q + cc);
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < SYM_ROWS; r0 += 8) {
+          double2 kv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double* p = Kr + (long long)(r0 + u) * N + cc;
+            kv[u].x = __builtin_nontemporal_load(p); kv[u].y = __builtin_nontemporal_load(p + 1);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            acc[r0 + u] = fma(kv[u].x, q2.x, fma(kv[u].y, q2.y, acc[r0 + u]));
+            z0 = fma(kv[u].x, qi[r0 + u], z0);
+            z1 = fma(kv[u].y, qi[r0 + u], z1);
+          }
+        }
+        if (off_diag) *reinterpret_cast<double2*>(Zs + cc) = make_double2(z0, z1);
+      }
+    }
+    c = cend + lane * 2;   // nothing left for the ragged-strip loop
+  }
+#pragma unroll 1
+  for (; c < cend; c += 128) {
     const bool in_tri = c >= i0;                  // i0 and SYM_ROWS are even: both columns of a lane agree
     const bool off_diag = c >= i0 + SYM_ROWS;
     if (!in_tri) continue;
@@ -344,13 +423,16 @@ __global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restr
   const int lane = threadIdx.x & 63;
   // readfirstlane makes the wave index provably uniform, so q_i of the strip and all row addresses live
   // in scalar registers
-  const long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long wi = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long w = wi >> 1;
+  const int half = (int)(wi & 1);
   const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
   const long long npairs = (nstrips + 1) / 2;
   if (w >= npairs) return;
-  quadform_sym_strip(K, q, yrow, Z, N, w, lane);
+  double* __restrict__ yh = yrow + half * N;     // row partials of this half (the reduce kernel adds the two)
+  quadform_sym_strip(K, q, yh, Z, N, w, lane, half);
   const long long s2 = nstrips - 1 - w;
-  if (s2 != w) quadform_sym_strip(K, q, yrow, Z, N, s2, lane);
+  if (s2 != w) quadform_sym_strip(K, q, yh, Z, N, s2, lane, half);
 }
 
 // y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j]; 64 columns per workgroup, the strips dealt to 4 waves and
@@ -364,7 +446,16 @@ __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* 
   double acc = 0.0;
   if (j < N) {
     const long long ns = j / SYM_ROWS;              // strips strictly above column j's own strip
-    for (long long s = wave; s < ns; s += 4)
+    // eight loads in flight per lane (the adds keep their order: the sum is the same as the plain loop's)
+    long long s = wave;
+    for (; s + 28 < ns; s += 32) {
+      double zv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) zv[u] = __builtin_nontemporal_load(Z + sym_z_offset(s + 4 * u, N) + (j - (s + 4 * u + 1) * SYM_ROWS));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += zv[u];
+    }
+    for (; s < ns; s += 4)
       acc += Z[sym_z_offset(s, N) + (j - (s + 1) * SYM_ROWS)];
   }
   part[wave][lane] = acc;
@@ -372,7 +463,7 @@ __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* 
   if (wave == 0) {
     double v = 0.0, contrib = 0.0;
     if (j < N) {
-      v = yrow[j] + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+      v = (yrow[j] + yrow[N + j]) + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
       if (y) y[j] = v;
       contrib = q[j] * v;
     }
@@ -385,7 +476,7 @@ size_t quadform_sym_workspace_doubles(int n) {
   const long long N = 1ll << n;
   const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
   const long long z = ns * N - (long long)SYM_ROWS * (ns * (ns + 1) / 2) + 2 * SYM_ROWS;   // all strips (+ slack)
-  return (size_t)(z > 0 ? z : 0) + (size_t)N /*yrow*/ + (size_t)((N + 63) / 64) /*partials*/ + 64;
+  return (size_t)(z > 0 ? z : 0) + (size_t)(2 * N) /*yrow, two halves*/ + (size_t)((N + 63) / 64) /*partials*/ + 64;
 }
 
 hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
@@ -393,11 +484,13 @@ hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* 
   const long long N = 1ll << n;
   const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
   double* yrow = ws;
-  double* partials = ws + N;
+  double* partials = ws + 2 * N;
   const long long nred = (N + 63) / 64;
   double* Z = partials + ((nred + 31) / 32) * 32;          // keep Z 16-byte aligned (N, offsets are even)
   const long long npairs = (ns + 1) / 2;
-  quadform_sym_kernel<<<(unsigned)((npairs + 3) / 4), 256, 0, st>>>(K, q, yrow, Z, N);
+  // (waves are independent: BORNVI_SYM_WAVES picks the workgroup size for co-residency experiments)
+  static const int sym_waves = [] { const char* e = getenv("BORNVI_SYM_WAVES"); int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
+  quadform_sym_kernel<<<(unsigned)((2 * npairs + sym_waves - 1) / sym_waves), 64 * sym_waves, 0, st>>>(K, q, yrow, Z, N);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z, q, y_or_null, partials, N);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <utility>
 
 namespace bornvi {
 
@@ -265,6 +266,9 @@ struct BuildSpec {
   int n_params = 0, n_gates = 0;
   bool in_state = false;   // first pass loads a canonical-order state instead of |0...0>
   bool out_state = false;  // last pass writes the canonical-order state instead of |psi|^2
+  // CNOTs (control, target) that end the circuit, in program order: not executed, applied to the outcome INDEX
+  // of the probabilities instead (|CX psi|^2 is a permutation of |psi|^2)
+  std::vector<std::pair<int, int>> out_perm;
 };
 bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::string& msg);
 }  // namespace
@@ -277,6 +281,15 @@ bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& plan
   BuildSpec spec;
   spec.n = n;
   fuse_gates(gates, n, spec.ops, spec.fused);
+  // Everything after the last one-qubit gate is CNOTs and CZs: the CZs only change phases (dropped), the CNOTs
+  // permute basis states (moved into the address the probabilities are written to).
+  {
+    size_t last_u = spec.ops.size();
+    while (last_u > 0 && spec.ops[last_u - 1].kind != K_U1) --last_u;
+    for (size_t q = last_u; q < spec.ops.size(); ++q)
+      if (spec.ops[q].kind == K_CX) spec.out_perm.push_back({spec.ops[q].a, spec.ops[q].b});
+    spec.ops.resize(last_u);
+  }
   spec.n_params = num_params(ansatz, n, layers);
   spec.n_gates = (int)gates.size();
   return build_plan(spec, opt, plan, msg);
@@ -302,7 +315,8 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
   const int n = spec.n;
   const std::vector<Op>& ops = spec.ops;
   const std::vector<Fused>& fused = spec.fused;
-  const int k = (n <= opt.kmax) ? n : std::min(opt.kmax, opt.kmulti);
+  const int kmulti = opt.kmulti > 0 ? opt.kmulti : (n <= 16 ? 11 : 12);
+  const int k = (n <= opt.kmax) ? n : std::min(opt.kmax, kmulti);
   const int r = std::min(opt.r, k);
   if (r > 4) { msg = "at most 4 register wires"; return false; }
   int threads = 64;
@@ -328,12 +342,23 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
   const int lo_can = std::min(opt.lo, k);
   std::vector<int> canon_low;  // wire at canonical physical bit p is n-1-p
   for (int p = 0; p < lo_can; ++p) canon_low.push_back(n - 1 - p);
+  // The last pass writes the canonical order.  If its target wires plus the lo_can lowest canonical wires do not
+  // fit in a tile, shorter contiguous runs (down to 2^3 elements) are accepted before a pure re-layout pass --
+  // a whole extra HBM round trip of every state -- is appended.
+  std::vector<int> canon_low_out = canon_low;
   {
-    std::vector<char> in(n, 0);
-    int cnt = 0;
-    for (int w : passes.back().targets) { in[w] = 1; ++cnt; }
-    for (int w : canon_low) if (!in[w]) { in[w] = 1; ++cnt; }
-    if (cnt > k) passes.push_back(PassInfo{});  // pure re-layout pass
+    auto count_with = [&](int lo) {
+      std::vector<char> in(n, 0);
+      int cnt = 0;
+      for (int w : passes.back().targets) { in[w] = 1; ++cnt; }
+      for (int p = 0; p < lo; ++p) if (!in[n - 1 - p]) { in[n - 1 - p] = 1; ++cnt; }
+      return cnt;
+    };
+    int lo_fit = -1;
+    for (int lo = lo_can; lo >= std::min(3, lo_can); --lo)
+      if (count_with(lo) <= k) { lo_fit = lo; break; }
+    if (lo_fit < 0) passes.push_back(PassInfo{});  // pure re-layout pass
+    else canon_low_out.resize(lo_fit);
   }
   if (spec.in_state) {
     std::vector<char> in(n, 0);
@@ -349,7 +374,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     std::vector<char> in(n, 0);
     auto add = [&](int w) { if (!in[w] && (int)P.local.size() < k) { in[w] = 1; P.local.push_back(w); } };
     for (int w : P.targets) add(w);
-    if (i == np - 1) for (int w : canon_low) add(w);
+    if (i == np - 1) for (int w : canon_low_out) add(w);
     if (i == 0 && spec.in_state) for (int w : canon_low) add(w);
     if (i + 1 < np) for (int w : passes[i + 1].targets) add(w);
     if (i > 0) for (int w : passes[i - 1].local) add(w);
@@ -368,7 +393,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     for (int w : P.local) if (!placed[w]) others.push_back(w);
     std::sort(others.begin(), others.end());
     for (int w : others) P.lds_wire.push_back(w);
-    if (i == np - 1) { P.out_low = canon_low; break; }
+    if (i == np - 1) { P.out_low = canon_low_out; break; }
     std::vector<char> nxt(n, 0);
     for (int w : passes[i + 1].local) nxt[w] = 1;
     std::vector<int> ldspos(n, -1);
@@ -493,6 +518,32 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
         uint32_t col = 0;
         for (int b2 = 0; b2 < k; ++b2) col |= ((fout[b2].g >> m) & 1u) << b2;
         put_half(PW_OUT_GMASK, m, lds_swizzle(col));
+      }
+      // phys-out address columns: where the index bit of each wire lands.  One-hot, except for the circuit-ending
+      // CNOTs of the last pass: wire w's bit is xor-ed into every wire the CNOT chain propagates it to.
+      std::vector<uint32_t> wire_col(n, 0);
+      for (int w = 0; w < n; ++w) wire_col[w] = 1u << layout[i][w];
+      if (i == np - 1 && !spec.out_perm.empty()) {
+        std::vector<uint32_t> reach(n);          // reach[w] = set of wires whose final bit contains bit w
+        std::vector<uint32_t> expr(n);           // expr[w] = set of original wire bits xor-ed into wire w
+        for (int w = 0; w < n; ++w) expr[w] = 1u << w;
+        for (const auto& cx : spec.out_perm) expr[cx.second] ^= expr[cx.first];
+        for (int w = 0; w < n; ++w) {
+          uint32_t col = 0;
+          for (int w2 = 0; w2 < n; ++w2) if ((expr[w2] >> w) & 1u) col ^= 1u << layout[i][w2];
+          wire_col[w] = col;
+        }
+      }
+      {
+        std::vector<char> isl2(n, 0);
+        int j2 = 0;
+        for (int w : P.out_low) { W[base + PW_OUT_COL + j2] = wire_col[w]; isl2[w] = 1; ++j2; }
+        for (int q = 0; q < k; ++q) {
+          const int w = P.lds_wire[q];
+          if (isl2[w]) continue;
+          W[base + PW_OUT_COL + j2] = wire_col[w]; ++j2;
+        }
+        for (int m = 0; m < n - k; ++m) W[base + PW_OUT_GCOL + m] = wire_col[P.global[m]];
       }
     }
     // ---- stages ----

@@ -56,7 +56,8 @@ constexpr int FUSED_WORDS = 2 + 2 * FUSED_MAX_ELEMS;
 // Without folded CNOTs IN_MASK[j] = lds_swizzle(1 << j); CNOTs at the head of the pass (targets tile-local)
 // are GF(2)-linear maps of the tile index and are folded into these masks -- they cost nothing.
 // Store: element v of the out enumeration is read from slot  xor_j bit_j(v) OUT_MASK[j] ^ xor_m bit_m(g) OUT_GMASK[m]
-// (CNOTs at the tail of the pass folded in) and written to  sum_j bit_j(v) << OUT_PHYS[j] | sum_m bit_m(g) << OUT_GPHYS[m].
+// (CNOTs at the tail of the pass folded in) and written to  sum_j bit_j(v) << OUT_PHYS[j] | sum_m bit_m(g) << OUT_GPHYS[m]
+// -- in general to the GF(2)-linear address given by the PW_OUT_COL / PW_OUT_GCOL columns (see there).
 enum PassWords : int {
   PW_FLAGS = 0, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS, PW_RESERVED,
   PW_IN_PHYS = 8,       // [16 bytes]
@@ -73,7 +74,11 @@ enum PassWords : int {
   PW_MATS = 128,        // [MAX_STAGES * 2 words] fused gate index of (stage s, register bit i), 16 bits each:
                         //   word PW_MATS + 2 s + (i >> 1); the workgroup copies these matrices of ITS circuit
                         //   into LDS (after the tile) while the tile loads are in flight
-  PW_STAGES = 128 + 2 * 32
+  PW_OUT_COL = 192,     // [16 words] phys-out address = xor_j bit_j(v) OUT_COL[j] ^ xor_m bit_m(g) OUT_GCOL[m]:
+  PW_OUT_GCOL = 208,    // [16 words]   one-hot columns (1 << OUT_PHYS[j]) except in the last pass of a circuit, where
+                        //   the CNOTs that END the circuit (only diagonal gates or CNOTs after them) are not
+                        //   executed at all: |psi|^2 is written to the permuted outcome index instead
+  PW_STAGES = 224
 };
 constexpr int MAX_STAGES = 32;          // stages per pass
 constexpr int STAGE_MATS_BYTES = 4 * 64; // LDS bytes of one stage's four 2x2 complex matrices
@@ -111,8 +116,9 @@ BORNVI_HD inline uint32_t lds_swizzle(uint32_t l) { return l ^ (((l >> 4) ^ (l >
 
 struct PlanOptions {
   int kmax = 13;     // largest tile (2^13 complex128 = 128 KiB of LDS): a state of n <= kmax qubits is ONE tile
-  int kmulti = 12;   // tile bits when the state needs several tiles (n > kmax): 64 KiB tiles let two
-                     // workgroups share a CU, so one's HBM phases overlap the other's LDS/FMA phases
+  int kmulti = 0;    // tile bits when the state needs several tiles (n > kmax).  0 = by measurement on MI355X
+                     // (DESIGN.md 4.1): 2^11 (32 KiB, four 128-thread workgroups per CU whose HBM, LDS and FMA
+                     // phases interleave) up to n = 16, 2^12 above (fewer passes over the larger states)
   int r = 4;         // register wires per stage (2^4 amplitudes per thread)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 512;

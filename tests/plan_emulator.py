@@ -14,7 +14,7 @@ PH_N, PH_K, PH_NPASSES, PH_NFUSED, PH_NPARAMS, PH_OFF_FUSED, PH_OFF_PASSTAB, PH_
 FUSED_WORDS = 10
 PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
 PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_IN_MASK, PW_IN_GMASK, PW_OUT_MASK, PW_OUT_GMASK = 8, 12, 16, 20, 24, 32, 40, 48
-PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_MATS, PW_STAGES = 64, 96, 128, 192
+PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_MATS, PW_OUT_COL, PW_OUT_GCOL, PW_STAGES = 64, 96, 128, 192, 208, 224
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
 STAGE_HDR_WORDS = 48
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
@@ -149,11 +149,12 @@ def run_plan(W, mats, state_in=None, fast=None):
         ksize = 1 << k
         out = np.zeros(N, dtype=np.complex128)
         probs = np.zeros(N)
+        written = np.zeros(N, dtype=np.int64)
         # structural checks the kernel relies on
         for j in range(lo_in):
             assert (flags & PASS_INIT) or tbyte(P, PW_IN_PHYS, j) == j
         for j in range(lo_out):
-            assert tbyte(P, PW_OUT_PHYS, j) == j
+            assert (flags & PASS_FINAL) or tbyte(P, PW_OUT_PHYS, j) == j
         for g in range(1 << (n - k)):
             u = np.arange(ksize, dtype=np.int64)
             if flags & PASS_INIT:
@@ -247,16 +248,32 @@ def run_plan(W, mats, state_in=None, fast=None):
             v = np.arange(ksize, dtype=np.int64)
             gvec = np.full(ksize, g, dtype=np.int64)
             lds = swz_inv(xor_map(v, k, P, PW_OUT_MASK) ^ xor_map(gvec, n - k, P, PW_OUT_GMASK))   # tail CNOTs folded in
+            # phys-out address: GF(2)-linear columns; one-hot (1 << OUT_PHYS) except where the circuit-ending
+            # CNOTs are applied to the outcome index of the probabilities (last pass)
             phys = np.zeros(ksize, dtype=np.int64)
             for j in range(k):
-                phys |= ((v >> j) & 1) << tbyte(P, PW_OUT_PHYS, j)
+                phys ^= ((v >> j) & 1) * int(P[PW_OUT_COL + j])
             for m in range(n - k):
-                phys |= ((g >> m) & 1) << tbyte(P, PW_OUT_GPHYS, m)
+                phys ^= ((g >> m) & 1) * int(P[PW_OUT_GCOL + m])
+            if not (flags & PASS_FINAL):
+                for j in range(k):
+                    assert int(P[PW_OUT_COL + j]) == 1 << tbyte(P, PW_OUT_PHYS, j)
+                for m in range(n - k):
+                    assert int(P[PW_OUT_GCOL + m]) == 1 << tbyte(P, PW_OUT_GPHYS, m)
+            # a 64-lane store covers one aligned run of 2^lo_out elements; with the circuit-ending CNOT ring in the
+            # address (its wrap-around CNOT puts the lanes' parity into the top bit) it splits over two runs whose
+            # other halves the neighbouring store instructions of the same wave fill
+            lanes = phys[: 1 << lo_out]
+            lowmask = (1 << lo_out) - 1
+            assert np.array_equal(np.sort(lanes & lowmask), np.arange(1 << lo_out))
+            assert len(np.unique(lanes & ~lowmask)) <= (2 if (flags & PASS_FINAL) else 1)
+            written[phys] += 1
             assert np.array_equal(np.sort(lds), np.arange(ksize))
             if flags & PASS_FINAL:
                 probs[phys] = np.abs(tile[lds]) ** 2
             else:
                 out[phys] = tile[lds]
+        assert np.all(written == 1)      # the phys-out map is a bijection
         buf = out
         if flags & PASS_FINAL:
             result = probs

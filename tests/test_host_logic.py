@@ -115,7 +115,7 @@ def test_full_size_plans_are_well_formed():
         for n, L in [(16, 6), (20, 8)]:
             W = _ext.plan_words(ansatz_id, n, L, 0)
             st = pe.plan_stats(W)
-            assert st["k"] == 12 and 2 <= st["passes"] <= 3 * L + 2
+            assert st["k"] == (11 if n <= 16 else 12) and 2 <= st["passes"] <= 3 * L + 2
             assert int(W[8]) == len(W)
     assert _ext.lib().bornvi_plan_describe(0, 31, 1, 0, None, 0) == -1       # n out of range
     assert _ext.lib().bornvi_plan_describe(9, 4, 1, 0, None, 0) == -1        # unknown ansatz
