@@ -128,6 +128,193 @@ static hipError_t launch_gram_nb(const double* S, double* K, const PowTable& apo
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// dense Gram on the matrix cores (n >= 8).  The bracket of the closed form above is a rank-(3n+2) bilinear
+// form in (i, j): with U_ib = T_ib (1 - 2 i_b) and alpha_i = -c_same sum_b T_ib - dc sum_b i_b T_ib,
+//   bracket = sum_b S_ib S_jb  +  sum_b (-dc U_ib) j_b  +  sum_b i_b (-dc U_jb)  +  (alpha_i + alpha_j)
+// i.e. three small GEMMs, run as chains of v_mfma_f64_16x16x4_f64 on 16 x 16 tiles.  They are kept in three
+// separate accumulators and combined as (acc1 + (acc2 + acc3)) + (alpha_i + alpha_j): acc1 is symmetric term
+// by term and acc2(i, j) == acc3(j, i) operation by operation, so K stays BITWISE symmetric (the symmetric
+// contraction relies on it).  a^d is applied in the epilogue.  HBM-write bound: 8 * 4^n bytes.
+// Workgroup = 4 waves, GM_ROWS rows x GM_COLS columns; the row factors sit in LDS for the whole workgroup, each
+// wave walks over 16-column tiles of its share, whose column factors it builds in its own LDS scratch.
+// Fragment layout of the f64 MFMA (cdna_hip_programming.md, section 3): A[row = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][col = lane & 15], D[row = (lane >> 4) + 4 r][col = lane & 15], r = 0..3.
+// ------------------------------------------------------------------------------------------------
+constexpr int GM_ROWS = 64, GM_COLS = 2048, GM_MAXN = 17;
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+struct GramFactorPitch {
+  int np, p, rowpitch;   // padded K of each of the three products; LDS pitch of one factor row; of one outcome
+};
+__host__ __device__ constexpr GramFactorPitch gram_pitch(int n) {
+  GramFactorPitch g{};
+  g.np = (n + 3) / 4 * 4;
+  g.p = g.np + 2;              // pitch = 2 (mod 4): the 16 rows x 2 k's a half-wave reads hit 32 distinct 8-byte banks
+  g.rowpitch = 3 * g.p + 4;    // F1 | F2 | F3 | alpha, again 2 (mod 4)
+  return g;
+}
+
+// the n scores of outcome z, all loads issued together (the column side fetches them one tile ahead)
+template <int n>
+__device__ __forceinline__ void gram_load_scores(const double* __restrict__ S, long long z, double (&sv)[GM_MAXN]) {
+#pragma unroll
+  for (int b = 0; b < GM_MAXN; ++b) sv[b] = (b < n) ? S[z * n + b] : 0.0;
+}
+
+// factors of one outcome index z into its LDS row: F1 = S_z,  F2 = -dc U_z,  F3 = bits(z) (each padded with zeros),
+// then alpha_z.  Row side and column side use this same function: alpha_z must be the same bits on both sides.
+template <int n>
+__device__ __forceinline__ void gram_factors(const double (&sv)[GM_MAXN], long long z, double c_same, double dc,
+                                             double* __restrict__ row) {
+  constexpr GramFactorPitch g = gram_pitch(n);
+  double rt = 0.0, ab = 0.0;
+#pragma unroll
+  for (int b = 0; b < g.np; ++b) {
+    if (b < n) {
+      const double t = sv[b] - 1.0;
+      const int bit = (int)((z >> (n - 1 - b)) & 1ll);
+      rt += t;
+      ab += bit ? t : 0.0;
+      row[b] = sv[b];
+      row[g.p + b] = -dc * (bit ? -t : t);
+      row[2 * g.p + b] = bit ? 1.0 : 0.0;
+    } else {
+      row[b] = 0.0; row[g.p + b] = 0.0; row[2 * g.p + b] = 0.0;
+    }
+  }
+  row[3 * g.p] = -c_same * rt - dc * ab;
+}
+
+template <int n>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ S, double* __restrict__ K,
+                                                        PowTable apow, double c_same, double dc, long long row_begin,
+                                                        long long row_end) {
+  extern __shared__ double gm_lds[];
+  __shared__ double apow_s[33];
+  constexpr GramFactorPitch g = gram_pitch(n);
+  constexpr int KK = g.np / 4;                          // MFMAs per product and tile
+  const long long N = 1ll << n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* __restrict__ Lt = gm_lds;                      // [GM_ROWS][rowpitch]
+  double* __restrict__ Rt = gm_lds + GM_ROWS * g.rowpitch + wave * 16 * g.rowpitch;   // this wave's [16][rowpitch]
+  if (threadIdx.x < 33) apow_s[threadIdx.x] = apow.v[threadIdx.x];
+  const long long i_blk = row_begin + (long long)blockIdx.y * GM_ROWS;
+  if (threadIdx.x < GM_ROWS) {
+    const long long i = i_blk + threadIdx.x;
+    double* r = Lt + threadIdx.x * g.rowpitch;
+    if (i < row_end) {
+      double sv[GM_MAXN];
+      gram_load_scores<n>(S, i, sv);
+      gram_factors<n>(sv, i, c_same, dc, r);
+    } else {
+      for (int b = 0; b < g.rowpitch; ++b) r[b] = 0.0;
+    }
+  }
+  __syncthreads();
+  const long long j_chunk = (long long)blockIdx.x * GM_COLS;
+  const long long j_chunk_end = (j_chunk + GM_COLS < N) ? j_chunk + GM_COLS : N;
+  const int ar = lane & 15, ak = lane >> 4;
+  double svn[GM_MAXN];     // scores of the NEXT column tile (lanes 0..15), in flight during this tile's MFMAs
+  long long j0 = j_chunk + wave * 16;
+  if (lane < 16 && j0 < j_chunk_end) gram_load_scores<n>(S, j0 + lane, svn);
+  for (; j0 < j_chunk_end; j0 += 64) {
+    // column factors of this 16-column tile -> the wave's scratch (lanes 0..15 one column each)
+    if (lane < 16) {
+      gram_factors<n>(svn, j0 + lane, c_same, dc, Rt + lane * g.rowpitch);
+      if (j0 + 64 < j_chunk_end) gram_load_scores<n>(S, j0 + 64 + lane, svn);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // B fragments of the three products (column side), kept in registers across the row tiles
+    double b1[KK], b2[KK], b3[KK];
+    const double* rj = Rt + ar * g.rowpitch;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      b1[kk] = rj[4 * kk + ak];
+      b2[kk] = rj[2 * g.p + 4 * kk + ak];   // pairs with the row side's F2: bits(j)
+      b3[kk] = rj[g.p + 4 * kk + ak];       // pairs with the row side's F3: -dc U_j
+    }
+    const double alpha_j = rj[3 * g.p];
+    const long long j = j0 + ar;
+#pragma unroll 1
+    for (int it = 0; it < GM_ROWS / 16; it += 2) {   // two row tiles at a time: six independent MFMA chains
+      const double* ri0 = Lt + (it * 16 + ar) * g.rowpitch;
+      const double* ri1 = ri0 + 16 * g.rowpitch;
+      d4_t a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1, c1 = a1, c2 = a1, c3 = a1;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri0[4 * kk + ak], b1[kk], a1, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri1[4 * kk + ak], b1[kk], c1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri0[g.p + 4 * kk + ak], b2[kk], a2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri1[g.p + 4 * kk + ak], b2[kk], c2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri0[2 * g.p + 4 * kk + ak], b3[kk], a3, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri1[2 * g.p + 4 * kk + ak], b3[kk], c3, 0, 0, 0);
+      }
+      // D layout: row = (lane >> 4) + 4 r, col = lane & 15
+      const long long ib = i_blk + it * 16 + ak;
+      const double* al0 = Lt + (it * 16 + ak) * g.rowpitch + 3 * g.p;   // alpha of row ak + 4 r: + 4 r rowpitch
+      double* __restrict__ Kp = K + (ib - row_begin) * N + j;
+      if (i_blk + GM_ROWS <= row_end) {     // whole row block inside the range (wave-uniform): no per-row tests
+        double w0[4], w1[4], e0[4], e1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          w0[r] = apow_s[__popcll((unsigned long long)((ib + 4 * r) ^ j))];
+          w1[r] = apow_s[__popcll((unsigned long long)((ib + 16 + 4 * r) ^ j))];
+          e0[r] = al0[4 * r * g.rowpitch] + alpha_j;
+          e1[r] = al0[(16 + 4 * r) * g.rowpitch] + alpha_j;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          __builtin_nontemporal_store(w0[r] * ((a1[r] + (a2[r] + a3[r])) + e0[r]), Kp + (long long)(4 * r) * N);
+          __builtin_nontemporal_store(w1[r] * ((c1[r] + (c2[r] + c3[r])) + e1[r]), Kp + (long long)(16 + 4 * r) * N);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long i = ib + 4 * r;
+          if (i < row_end)
+            K[(i - row_begin) * N + j] = apow_s[__popcll((unsigned long long)(i ^ j))] *
+                                         ((a1[r] + (a2[r] + a3[r])) + (al0[4 * r * g.rowpitch] + alpha_j));
+          if (i + 16 < row_end)
+            K[(i + 16 - row_begin) * N + j] = apow_s[__popcll((unsigned long long)((i + 16) ^ j))] *
+                                              ((c1[r] + (c2[r] + c3[r])) + (al0[(16 + 4 * r) * g.rowpitch] + alpha_j));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();     // the scratch is rewritten by the next tile
+  }
+}
+
+template <int NB>
+static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc,
+                                      long long row_begin, long long row_end, hipStream_t st) {
+  const long long N = 1ll << NB;
+  if (row_end <= row_begin) return hipSuccess;
+  constexpr GramFactorPitch g = gram_pitch(NB);
+  const size_t lds = (size_t)(GM_ROWS + 4 * 16) * g.rowpitch * sizeof(double);
+  static bool prepared = false;
+  if (!prepared) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_mfma_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    prepared = true;
+  }
+  const long long cols = N < GM_COLS ? N : GM_COLS;
+  dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - row_begin + GM_ROWS - 1) / GM_ROWS));
+  gram_mfma_kernel<NB><<<grid, 256, lds, st>>>(S, K, apow, c_same, dc, row_begin, row_end);
+  return hipGetLastError();
+}
+
+static hipError_t launch_gram_mfma(int n, const double* S, double* K, const PowTable& apow, double c_same, double dc,
+                                   long long row_begin, long long row_end, hipStream_t st) {
+  switch (n) {
+#define BORNVI_GM_CASE(NB) case NB: return launch_gram_mfma_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, st);
+    BORNVI_GM_CASE(8) BORNVI_GM_CASE(9) BORNVI_GM_CASE(10) BORNVI_GM_CASE(11) BORNVI_GM_CASE(12) BORNVI_GM_CASE(13)
+    BORNVI_GM_CASE(14) BORNVI_GM_CASE(15) BORNVI_GM_CASE(16) BORNVI_GM_CASE(17)
+#undef BORNVI_GM_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, long long row_begin,
                              long long row_end, hipStream_t st) {
   PowTable apow;
@@ -136,6 +323,9 @@ hipError_t launch_gram_build(int n, double length_scale, const double* S, double
   const double a = apow.v[1];
   const double c_same = 1.0 - a, c_diff = 1.0 - 1.0 / a;
   const double dc = c_diff - c_same;
+  // matrix-core path for n >= 8 (2^n >= 256: whole 16 x 16 tiles); BORNVI_GRAM_VALU=1 keeps the VALU kernel (A/B)
+  static const bool force_valu = [] { const char* e = getenv("BORNVI_GRAM_VALU"); return e && e[0] == '1'; }();
+  if (n >= 8 && n <= GM_MAXN && !force_valu) return launch_gram_mfma(n, S, K, apow, c_same, dc, row_begin, row_end, st);
   switch (n) {
 #define BORNVI_GRAM_CASE(NB) case NB: return launch_gram_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, st);
     BORNVI_GRAM_CASE(1) BORNVI_GRAM_CASE(2) BORNVI_GRAM_CASE(3) BORNVI_GRAM_CASE(4) BORNVI_GRAM_CASE(5)
