@@ -216,7 +216,7 @@ def main():
         # algorithmic bytes: 32 * 2^n per gate per state; dense contraction 8 * 4^n
         circ_bytes = 32.0 * N * n_gates * circuits_rank
         rows_rank = -(-N // world)
-        sym = gram_mode == "dense" and world == 1 and vi.symmetric_contraction
+        sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
         stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
         stein_bytes = 8.0 * N * rows_rank if gram_mode == "dense" else 16.0 * N * n * (n + 1)
         # real HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.sh), recorded
@@ -225,7 +225,10 @@ def main():
         pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic_n16_L6_dense.json")
         if args.workload == "n16_L6_dense" and world == 1 and not args.tile_bits and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))["kernels"]
-        t_circ = pmc.get("circuit_pass_kernel<true, false>", {}).get("hbm_bytes_per_launch")
+        t_circ = None
+        for kname, kv in pmc.items():
+            if kname.startswith("circuit_pass"):
+                t_circ = kv.get("hbm_bytes_per_launch")
         t_stein = None
         if sym and "quadform_sym_kernel" in pmc:
             t_stein = pmc["quadform_sym_kernel"]["hbm_bytes_per_launch"] + pmc["quadform_sym_reduce_kernel"]["hbm_bytes_per_launch"]
@@ -264,7 +267,8 @@ def main():
             "config": {"workload": args.workload, "n_qubits": n, "layers": layers, "ansatz": ansatz,
                        "params": P, "circuits_per_step": 1 + 2 * P, "gates_per_circuit": n_gates,
                        "gram": gram_mode, "bayesian_network": f"synthetic n={n} seed=0 (SURVEY 8d)",
-                       "optimizer": "adam lr=0.005 cosine clip=10", "parallelism": f"paramshift+gram-rows shard x{world}",
+                       "optimizer": "adam lr=0.005 cosine clip=10",
+                       "parallelism": f"paramshift + gram {'strip-pair' if vi._K_pairs is not None else 'row'} shard x{world}",
                        "dist_backend": dist_backend if world > 1 else None,
                        "tile_bits": int(plan[2]), "passes": n_passes},
             "roofline": roof, "kernels": kern,

@@ -165,6 +165,19 @@ int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const dou
                               double* ksd2, double* y, void* workspace, size_t workspace_bytes,
                               bornvi_stream stream);
 
+/* Strip-pair shard of the symmetric form (several GPUs, each reading only its part of the UPPER triangle).
+ * The rows are cut into strips of bornvi_stein_sym_strip_rows() rows; pair p = strips p and n_strips-1-p (a long
+ * and a short part of the triangle).  A GPU owning pairs [pair_begin, pair_end) holds K_lo = rows of the strips
+ * [pair_begin, pair_end) and K_hi = rows of the strips [n_strips - pair_end, n_strips - pair_begin) (each block
+ * built with bornvi_stein_gram_build_rows) and gets y_partial dev [2^n] and ksd2_partial dev [1]: its additive
+ * share of K q and of q^T K q; the sum over the GPUs (one all-reduce of 2^n + 1 doubles) is the full result.
+ * Workspace as bornvi_stein_quadform_sym. */
+int bornvi_stein_sym_strip_rows(void);
+int bornvi_stein_quadform_sym_pairs(bornvi_handle h, int n, const double* K_lo, const double* K_hi,
+                                    long long pair_begin, long long pair_end, const double* q,
+                                    double* ksd2_partial, double* y_partial, void* workspace,
+                                    size_t workspace_bytes, bornvi_stream stream);
+
 /* Row-sharded form: K_rows holds rows [row_begin, row_end); q dev [2^n] (full);
  * y_rows dev [row_end - row_begin] = those rows of K q (or NULL); ksd2_partial dev [1] =
  * sum over them of q_i y_i.  Workspace as bornvi_stein_quadform. */

@@ -67,6 +67,9 @@ _PROTOS = {
     "bornvi_stein_quadform_sym_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "bornvi_stein_quadform_sym": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_stein_sym_strip_rows": (C.c_int, []),
+    "bornvi_stein_quadform_sym_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_stein_matvec_kron_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "bornvi_stein_matvec_kron": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

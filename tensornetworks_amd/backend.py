@@ -196,15 +196,55 @@ def score_from_packed(packed, n, dev):
     return S, pxz
 
 
-def stein_gram(S, n, length_scale=1.0, rows=None):
-    """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard)."""
+def stein_gram(S, n, length_scale=1.0, rows=None, out=None):
+    """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard); `out`:
+    a contiguous [rows, 2^n] float64 destination (e.g. a slice of a larger buffer)."""
     dev = S.device
     h = _ext.handle_for(dev)
     _chk(S, torch.float64, dev, "S")
     r0, r1 = (0, 1 << n) if rows is None else (int(rows[0]), int(rows[1]))
-    K = torch.empty((r1 - r0, 1 << n), dtype=torch.float64, device=dev)
+    K = torch.empty((r1 - r0, 1 << n), dtype=torch.float64, device=dev) if out is None else out
+    if out is not None:
+        _chk(out, torch.float64, dev, "out")
+        if tuple(out.shape) != (r1 - r0, 1 << n):
+            raise _ext.BornviError("stein_gram: `out` must be [rows, 2^n]")
     h.call("bornvi_stein_gram_build_rows", n, float(length_scale), _ptr(S), r0, r1, _ptr(K), _ext.stream_ptr(dev))
     return K
+
+
+def sym_pair_shard(n, rank, world_size):
+    """Strip pairs [pa, pb) of the symmetric contraction owned by `rank`, and the two row ranges they cover:
+    ((pa, pb), (rows_lo_begin, rows_lo_end), (rows_hi_begin, rows_hi_end)).  None when 2^n is too small to cut
+    into whole strip pairs for every rank (the row shard is used then)."""
+    R = int(_ext.lib().bornvi_stein_sym_strip_rows())
+    N = 1 << n
+    if N % (2 * R) != 0:
+        return None
+    ns = N // R
+    npairs = ns // 2
+    chunk = -(-npairs // world_size)
+    pa = min(npairs, rank * chunk)
+    pb = min(npairs, pa + chunk)
+    return (pa, pb), (pa * R, pb * R), ((ns - pb) * R, (ns - pa) * R)
+
+
+def stein_quadform_sym_pairs(K_lo, K_hi, pa, pb, q, n, out=None):
+    """This GPU's additive share of (K q, q^T K q) from its strip pairs [pa, pb) of the upper triangle:
+    returns a [2^n + 1] vector (y_partial followed by ksd2_partial) -- the message of the all-reduce."""
+    dev = q.device
+    h = _ext.handle_for(dev)
+    _chk(q, torch.float64, dev, "q")
+    if pb > pa:
+        _chk(K_lo, torch.float64, dev, "K_lo")
+        _chk(K_hi, torch.float64, dev, "K_hi")
+    N = 1 << n
+    if out is None:
+        out = torch.empty(N + 1, dtype=torch.float64, device=dev)
+    ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
+    h.call("bornvi_stein_quadform_sym_pairs", n, _ptr(K_lo) if pb > pa else None, _ptr(K_hi) if pb > pa else None,
+           int(pa), int(pb), _ptr(q), C.c_void_p(out.data_ptr() + 8 * N), _ptr(out), _ptr(ws), ws.numel(),
+           _ext.stream_ptr(dev))
+    return out
 
 
 def stein_quadform_rows(K_rows, r0, r1, q, n, out=None):

@@ -413,6 +413,26 @@ int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const dou
   return BORNVI_OK;
 }
 
+int bornvi_stein_sym_strip_rows(void) { return quadform_sym_rows_per_strip(); }
+
+int bornvi_stein_quadform_sym_pairs(bornvi_handle h, int n, const double* K_lo, const double* K_hi, long long pair_begin,
+                                    long long pair_end, const double* q, double* ksd2_partial, double* y_partial,
+                                    void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!q || !ksd2_partial || !y_partial) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  const long long N = 1ll << n, R = quadform_sym_rows_per_strip();
+  const long long ns = (N + R - 1) / R, npairs = (ns + 1) / 2;
+  if (pair_begin < 0 || pair_end < pair_begin || pair_end > npairs) return fail(h, BORNVI_ERR_INVALID, "strip-pair range out of bounds");
+  if (pair_end > pair_begin && (!K_lo || !K_hi)) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
+    return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_quadform_sym_pairs(n, K_lo, K_hi, pair_begin, pair_end, q, y_partial, ksd2_partial, (double*)workspace,
+                                      (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
 size_t bornvi_stein_matvec_kron_workspace_bytes(bornvi_handle h, int n) {
   if (!h || n < 1 || n > 30) return 0;
   DevPlan* dp = nullptr;

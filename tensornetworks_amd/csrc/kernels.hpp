@@ -41,6 +41,9 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 size_t quadform_sym_workspace_doubles(int n);
 hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2, double* ws,
                                hipStream_t st);
+hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long pair_begin, long long pair_end,
+                                     const double* q, double* y_or_null, double* ksd2, double* ws, hipStream_t st);
+int quadform_sym_rows_per_strip();
 // matrix-free mat-vec helpers
 hipError_t launch_kron_pack(int n, double length_scale, const double* S, const double* q,
                             double* packed /*complex [(n+2)/2, 2^n]*/, double* gate /*[8]*/, hipStream_t st);

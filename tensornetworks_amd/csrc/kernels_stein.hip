@@ -478,18 +478,20 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 // Traffic: 8 * N^2 / 2 (+ one diagonal block per strip) + 2 * 8 * N^2 / (2 SYM_ROWS) bytes.
 // ------------------------------------------------------------------------------------------------
 constexpr int SYM_ROWS = 32;
+constexpr int SYM_MAX_PARTS = 16;   // column pieces per strip (row-partial buffers in the workspace)
 
 __device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
   return s * N - (long long)SYM_ROWS * (s * (s + 1) / 2);   // Z_s[j - (s+1) SYM_ROWS] lives at this base
 }
 
 // one strip: rows [s SYM_ROWS, (s+1) SYM_ROWS), columns >= s SYM_ROWS
-// `half` (0 / 1): the strip's column range is cut in two (at a multiple of 128) and each half is its own work
-// item with its own row partials, so that twice as many waves stream (two per SIMD hide each other's
-// load-batch latency: one wave per SIMD left HBM idle while it ran its FMAs)
-__device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ K, const double* __restrict__ q,
-                                                   double* __restrict__ yrow, double* __restrict__ Z, long long N,
-                                                   long long s, int lane, int half) {
+// `part` of `nparts` (a power of two, 2 .. SYM_MAX_PARTS): the strip's column range is cut into nparts pieces (at
+// multiples of 128) and each piece is its own work item with its own row partials, so that enough waves stream
+// whatever the share of the triangle a launch covers (one GPU: 2 parts = 4096 waves; 1/8 of the pairs: 16 parts)
+__device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr /* first row of the strip */,
+                                                   const double* __restrict__ q, double* __restrict__ yrow,
+                                                   double* __restrict__ Z, long long N, long long s, int lane, int part,
+                                                   int nparts) {
   const long long i0 = s * SYM_ROWS;
   const int nrows = (int)((N - i0 < SYM_ROWS) ? N - i0 : SYM_ROWS);
   double qi[SYM_ROWS];
@@ -499,10 +501,9 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ K,
 #pragma unroll
   for (int r = 0; r < SYM_ROWS; ++r) acc[r] = 0.0;
   double* __restrict__ Zs = Z + sym_z_offset(s, N) - (i0 + SYM_ROWS);   // so that Zs[j] is the entry of column j
-  const double* __restrict__ Kr = K + i0 * N;
   const long long cstart = (i0 / 128) * 128;
-  const long long cmid = cstart + ((N - cstart) / 256) * 128;
-  const long long cbeg = half ? cmid : cstart, cend = half ? N : cmid;
+  const long long cpiece = ((N - cstart) / (128 * nparts)) * 128;
+  const long long cbeg = cstart + part * cpiece, cend = (part == nparts - 1) ? N : cbeg + cpiece;
   // main loop: 512 columns per trip = 4 KiB contiguous per row (8 rows x 4 chunks = 32 loads in flight; with
   // 1 KiB per row and 32 rows in flight every load of a batch opened a different DRAM page 512 KiB apart)
   long long c = cbeg + lane * 2;
@@ -607,53 +608,71 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ K,
   }
 }
 
-// wave w owns strips w and nstrips-1-w: a long and a short one, so every wave streams ~N + SYM_ROWS columns
-__global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restrict__ K, const double* __restrict__ q,
-                                                           double* __restrict__ yrow, double* __restrict__ Z, long long N) {
+// wave w owns strips w and nstrips-1-w: a long and a short one, so every wave streams ~N + SYM_ROWS columns.
+// Strip-pair shard (several GPUs): this launch covers the pairs [pair_begin, pair_end); K_lo holds the rows of the
+// strips [pair_begin, pair_end), K_hi those of the mirrored strips [nstrips - pair_end, nstrips - pair_begin).
+// (One GPU: pair range = all pairs, K_lo = K, K_hi = K + (nstrips - npairs) SYM_ROWS N.)
+__global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restrict__ K_lo, const double* __restrict__ K_hi,
+                                                           long long pair_begin, long long pair_end,
+                                                           const double* __restrict__ q, double* __restrict__ yrow,
+                                                           double* __restrict__ Z, long long N, int nparts_log2) {
   const int lane = threadIdx.x & 63;
   // readfirstlane makes the wave index provably uniform, so q_i of the strip and all row addresses live
   // in scalar registers
   const long long wi = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long w = wi >> 1;
-  const int half = (int)(wi & 1);
+  const long long w = pair_begin + (wi >> nparts_log2);
+  const int nparts = 1 << nparts_log2;
+  const int part = (int)(wi & (nparts - 1));
   const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
-  const long long npairs = (nstrips + 1) / 2;
-  if (w >= npairs) return;
-  double* __restrict__ yh = yrow + half * N;     // row partials of this half (the reduce kernel adds the two)
-  quadform_sym_strip(K, q, yh, Z, N, w, lane, half);
+  if (w >= pair_end) return;
+  double* __restrict__ yh = yrow + part * N;     // row partials of this part (the reduce kernel adds them up)
+  quadform_sym_strip(K_lo + (w - pair_begin) * SYM_ROWS * N, q, yh, Z, N, w, lane, part, nparts);
   const long long s2 = nstrips - 1 - w;
-  if (s2 != w) quadform_sym_strip(K, q, yh, Z, N, s2, lane, half);
+  if (s2 != w) quadform_sym_strip(K_hi + (s2 - (nstrips - pair_end)) * SYM_ROWS * N, q, yh, Z, N, s2, lane, part, nparts);
 }
 
 // y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j]; 64 columns per workgroup, the strips dealt to 4 waves and
 // combined through LDS in wave order; also the per-workgroup partial of q . y.
+// With a strip-pair shard only the strips [lo0, lo1) and [hi0, hi1) belong to this GPU: the sums run over those
+// (and yrow counts only where column j's own strip is one of them); y is then this GPU's PARTIAL of K q.
 __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* __restrict__ yrow, const double* __restrict__ Z,
                                                                   const double* __restrict__ q, double* __restrict__ y,
-                                                                  double* __restrict__ partials, long long N) {
+                                                                  double* __restrict__ partials, long long N,
+                                                                  long long lo0, long long lo1, long long hi0, long long hi1,
+                                                                  int nparts) {
   __shared__ double part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long j = (long long)blockIdx.x * 64 + lane;
   double acc = 0.0;
   if (j < N) {
-    const long long ns = j / SYM_ROWS;              // strips strictly above column j's own strip
-    // eight loads in flight per lane (the adds keep their order: the sum is the same as the plain loop's)
-    long long s = wave;
-    for (; s + 28 < ns; s += 32) {
-      double zv[8];
+    const long long sj = j / SYM_ROWS;              // strips strictly above column j's own strip contribute
+#pragma unroll 1
+    for (int rg = 0; rg < 2; ++rg) {
+      const long long r0 = rg ? hi0 : lo0;
+      const long long ns = rg ? (hi1 < sj ? hi1 : sj) : (lo1 < sj ? lo1 : sj);
+      // eight loads in flight per lane (the adds keep their order: the sum is the same as the plain loop's)
+      long long s = r0 + wave;
+      for (; s + 28 < ns; s += 32) {
+        double zv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) zv[u] = __builtin_nontemporal_load(Z + sym_z_offset(s + 4 * u, N) + (j - (s + 4 * u + 1) * SYM_ROWS));
+        for (int u = 0; u < 8; ++u) zv[u] = __builtin_nontemporal_load(Z + sym_z_offset(s + 4 * u, N) + (j - (s + 4 * u + 1) * SYM_ROWS));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += zv[u];
+        for (int u = 0; u < 8; ++u) acc += zv[u];
+      }
+      for (; s < ns; s += 4)
+        acc += Z[sym_z_offset(s, N) + (j - (s + 1) * SYM_ROWS)];
     }
-    for (; s < ns; s += 4)
-      acc += Z[sym_z_offset(s, N) + (j - (s + 1) * SYM_ROWS)];
   }
   part[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
     double v = 0.0, contrib = 0.0;
     if (j < N) {
-      v = (yrow[j] + yrow[N + j]) + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+      const long long sj = j / SYM_ROWS;
+      const bool own = (sj >= lo0 && sj < lo1) || (sj >= hi0 && sj < hi1);
+      double yr = 0.0;
+      if (own) for (int p = 0; p < nparts; ++p) yr += yrow[(long long)p * N + j];
+      v = yr + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
       if (y) y[j] = v;
       contrib = q[j] * v;
     }
@@ -666,29 +685,49 @@ size_t quadform_sym_workspace_doubles(int n) {
   const long long N = 1ll << n;
   const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
   const long long z = ns * N - (long long)SYM_ROWS * (ns * (ns + 1) / 2) + 2 * SYM_ROWS;   // all strips (+ slack)
-  return (size_t)(z > 0 ? z : 0) + (size_t)(2 * N) /*yrow, two halves*/ + (size_t)((N + 63) / 64) /*partials*/ + 64;
+  return (size_t)(z > 0 ? z : 0) + (size_t)(SYM_MAX_PARTS * N) /*yrow per column piece*/ + (size_t)((N + 63) / 64) /*partials*/ + 64;
+}
+
+// pairs [pair_begin, pair_end) of the N / SYM_ROWS / 2 strip pairs; K_lo / K_hi as in quadform_sym_kernel.
+// ksd2 = sum_j q_j y_j over the (partial) y of this launch.
+hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long pair_begin, long long pair_end,
+                                     const double* q, double* y_or_null, double* ksd2, double* ws, hipStream_t st) {
+  const long long N = 1ll << n;
+  const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
+  double* yrow = ws;
+  double* partials = ws + SYM_MAX_PARTS * N;
+  const long long nred = (N + 63) / 64;
+  double* Z = partials + ((nred + 31) / 32) * 32;          // keep Z 16-byte aligned (N, offsets are even)
+  const long long npairs = pair_end - pair_begin;
+  int parts_log2 = 1;                                       // enough column pieces for >= 4096 streaming waves
+  while ((1 << parts_log2) < SYM_MAX_PARTS && (npairs << parts_log2) < 4096) ++parts_log2;
+  const int nparts = 1 << parts_log2;
+  // (waves are independent: BORNVI_SYM_WAVES picks the workgroup size for co-residency experiments)
+  static const int sym_waves = [] { const char* e = getenv("BORNVI_SYM_WAVES"); int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
+  if (npairs > 0) {
+    quadform_sym_kernel<<<(unsigned)((nparts * npairs + sym_waves - 1) / sym_waves), 64 * sym_waves, 0, st>>>(
+        K_lo, K_hi, pair_begin, pair_end, q, yrow, Z, N, parts_log2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  long long hi0 = ns - pair_end, hi1 = ns - pair_begin;
+  if (hi0 < pair_end) hi0 = pair_end;                       // odd strip count: the middle strip is its own mirror
+  quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z, q, y_or_null, partials, N, pair_begin, pair_end, hi0, hi1, nparts);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  sum_partials_kernel<<<1, 256, 0, st>>>(partials, nred, ksd2);
+  return hipGetLastError();
 }
 
 hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
                                double* ws, hipStream_t st) {
   const long long N = 1ll << n;
   const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
-  double* yrow = ws;
-  double* partials = ws + 2 * N;
-  const long long nred = (N + 63) / 64;
-  double* Z = partials + ((nred + 31) / 32) * 32;          // keep Z 16-byte aligned (N, offsets are even)
   const long long npairs = (ns + 1) / 2;
-  // (waves are independent: BORNVI_SYM_WAVES picks the workgroup size for co-residency experiments)
-  static const int sym_waves = [] { const char* e = getenv("BORNVI_SYM_WAVES"); int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
-  quadform_sym_kernel<<<(unsigned)((2 * npairs + sym_waves - 1) / sym_waves), 64 * sym_waves, 0, st>>>(K, q, yrow, Z, N);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z, q, y_or_null, partials, N);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  sum_partials_kernel<<<1, 256, 0, st>>>(partials, nred, ksd2);
-  return hipGetLastError();
+  return launch_quadform_sym_pairs(n, K, K + (ns - npairs) * SYM_ROWS * N, 0, npairs, q, y_or_null, ksd2, ws, st);
 }
+
+int quadform_sym_rows_per_strip() { return SYM_ROWS; }
 
 // ------------------------------------------------------------------------------------------------
 // matrix-free y = K_p q.  The n+1 real vectors v_0 = q, v_{b+1} = s_b o q

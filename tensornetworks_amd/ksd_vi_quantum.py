@@ -102,7 +102,8 @@ class KSDVariationalInference:
         self._score_function_cache = {}
         self._S = None          # scores [2^n, n] on the GPU
         self._K = None          # dense Gram (dense mode): all rows, or this rank's row block when sharded
-        self._K_rows = None     # (row_begin, row_end) held in self._K
+        self._K_rows = None     # (row_begin, row_end) held in self._K (row shard)
+        self._K_pairs = None    # (pair_begin, pair_end, rows of the lower block) held in self._K (strip-pair shard)
         self._stein_key = None
         self.timers = None      # optional {name: [(start_event, end_event), ...]} filled by ksd_and_grad
         self.symmetric_contraction = True   # dense mode: contract with the upper triangle of K_p only
@@ -158,10 +159,22 @@ class KSDVariationalInference:
         self._S = score_matrix(self.bn, x_dict, self.latent_vars_names, device=dev)
         self._K = None
         self._K_rows = None
+        self._K_pairs = None
         if self._use_dense():
             rank, ws = shard.world(self.process_group)
-            self._K_rows = shard.shard_range(1 << n, rank, ws)
-            self._K = backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
+            sp = backend.sym_pair_shard(n, rank, ws) if (ws > 1 and self.symmetric_contraction) else None
+            if sp is not None:
+                # strip-pair shard of the symmetric contraction: this rank keeps two row blocks of K_p (a long and
+                # a short part of the upper triangle) and reads only 1/W of the triangle per step
+                (pa, pb), (l0, l1), (h0, h1) = sp
+                self._K = torch.empty(((l1 - l0) + (h1 - h0), 1 << n), dtype=torch.float64, device=dev)
+                if l1 > l0:
+                    backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(l0, l1), out=self._K[: l1 - l0])
+                    backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(h0, h1), out=self._K[l1 - l0:])
+                self._K_pairs = (pa, pb, l1 - l0)
+            else:
+                self._K_rows = shard.shard_range(1 << n, rank, ws)
+                self._K = backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
         self._stein_key = self._key(x_dict)
 
     def _timed(self, name):
@@ -173,6 +186,12 @@ class KSDVariationalInference:
         if self._K is None:
             return backend.stein_matvec_kron(self._S, q, n, self.base_kernel_length_scale)
         rank, ws = shard.world(self.process_group)
+        if self._K_pairs is not None:
+            # every rank adds its share of (K q, q.y); one all-reduce of 2^n + 1 doubles
+            pa, pb, nlo = self._K_pairs
+            msg = backend.stein_quadform_sym_pairs(self._K[:nlo], self._K[nlo:], pa, pb, q, n)
+            shard.all_reduce_sum(msg, self.process_group)
+            return msg[1 << n:], msg[: 1 << n]
         r0, r1 = self._K_rows
         if ws == 1:
             if self.symmetric_contraction:      # K_p from our builder is bitwise symmetric: read half of it

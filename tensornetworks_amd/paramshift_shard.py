@@ -44,6 +44,19 @@ def all_gather_flat(out, msg, group=None):
     return out
 
 
+def all_reduce_sum(msg, group=None):
+    """In-place sum over the ranks of a float64 vector (the partial K q of the strip-pair shard); every rank ends
+    with the same bits.  'gloo' groups with device tensors stage through host memory like all_gather_flat."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and msg.is_cuda:
+        host = msg.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        msg.copy_(host)
+    else:
+        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+    return msg
+
+
 def all_gather_grad(local_grad, num_params, group=None):
     """local_grad: this rank's slice (float64, any device the backend supports) -> full [P] vector,
     identical on every rank."""

@@ -121,6 +121,36 @@ def test_symmetric_quadform_equals_full(be, dev, n):
     np.testing.assert_allclose(y_sym.cpu().numpy(), K.cpu().numpy() @ q.cpu().numpy(), rtol=0, atol=1e-13 * scale)
 
 
+@pytest.mark.parametrize("n,world", [(6, 1), (7, 2), (8, 2), (10, 3), (12, 8), (13, 4)])
+def test_sym_strip_pair_shard_sums_to_full(be, dev, n, world):
+    """Several GPUs: each rank holds two row blocks of K_p (its strip pairs of the upper triangle) and computes
+    an additive share of (K q, q^T K q); the shares (what the all-reduce sums) add up to the full contraction."""
+    bn, lat, obs, x = synthetic_network(n, 2)
+    S, _ = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    K = be.stein_gram(S, n, 1.0)
+    g = torch.Generator().manual_seed(n)
+    q = torch.rand(2 ** n, generator=g, dtype=torch.float64).to(dev)
+    q /= q.sum()
+    k_ref, y_ref = be.stein_quadform_sym(K, q, n)
+    total = torch.zeros(2 ** n + 1, dtype=torch.float64, device=dev)
+    rows_seen = 0
+    for rank in range(world):
+        sp = be.sym_pair_shard(n, rank, world)
+        assert sp is not None
+        (pa, pb), (l0, l1), (h0, h1) = sp
+        K_lo = be.stein_gram(S, n, 1.0, rows=(l0, l1)) if l1 > l0 else None
+        K_hi = be.stein_gram(S, n, 1.0, rows=(h0, h1)) if h1 > h0 else None
+        if l1 > l0:       # the blocks a rank builds are the rows of the full matrix, bit for bit
+            assert torch.equal(K_lo, K[l0:l1]) and torch.equal(K_hi, K[h0:h1])
+        rows_seen += (l1 - l0) + (h1 - h0)
+        total += be.stein_quadform_sym_pairs(K_lo, K_hi, pa, pb, q, n)
+    assert rows_seen == 2 ** n
+    scale = (K.abs() @ q).max().item()
+    assert (total[:-1] - y_ref).abs().max().item() <= 1e-13 * scale
+    assert abs(total[-1].item() - k_ref.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
+    assert be.sym_pair_shard(5, 0, 2) is None       # 32 outcomes: one strip, no pairs to deal out
+
+
 def test_length_scale(be, dev):
     g = golden("synthetic_n5_s0.npz")
     S = torch.as_tensor(g["S"], device=dev)

@@ -13,6 +13,7 @@ shard.world = lambda group=None: (0, W)
 def fake_flat(out, msg, group=None):
     out.zero_(); out.view(W, -1)[0].copy_(msg); return out
 shard.all_gather_flat = fake_flat
+shard.all_reduce_sum = lambda msg, group=None: msg
 bn, lat, obs, x = synthetic_network(n, 0)
 torch.manual_seed(0)
 vi = KSDVariationalInference(bn, lat, obs, n, L, pytorch_device='cuda:0', gram_mode='dense')
