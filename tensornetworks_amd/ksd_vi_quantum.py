@@ -26,7 +26,7 @@ import torch.optim as optim
 from . import backend
 from . import paramshift_shard as shard
 from .quantum_born_machine import QuantumBornMachine
-from .stein_utils import base_hamming_kernel_torch, score_matrix, stein_gram_matrix
+from .stein_utils import base_hamming_kernel_torch, score_matrix, stein_gram_matrix, tvd_table
 from .utils import calculate_tvd, generate_all_binary_outcomes
 
 DENSE_GRAM_MAX_N = 16     # 8 * 4^16 bytes = 32 GiB of the 288 GB HBM; beyond that the matrix-free form
@@ -348,8 +348,14 @@ class KSDVariationalInference:
             history['grad_norm'].append(grad_norm if grad_norm is not None else 0.0)
 
             if true_posterior_for_tvd is not None:
-                current_q_dist_dict = self.born_machine.get_prob_dict(x_condition=qbm_x_condition_input)
-                tvd = calculate_tvd(true_posterior_for_tvd, current_q_dist_dict)
+                if torch.is_tensor(true_posterior_for_tvd):
+                    # array form (stein_utils.true_posterior_table): no dict of 2^n tuples; like the reference the
+                    # distribution AFTER this epoch's update is compared (one more circuit, :168)
+                    q_now = self.born_machine.get_probabilities(x_condition=qbm_x_condition_input).detach().squeeze()
+                    tvd = float(tvd_table(true_posterior_for_tvd.to(q_now.device), q_now))
+                else:
+                    current_q_dist_dict = self.born_machine.get_prob_dict(x_condition=qbm_x_condition_input)
+                    tvd = calculate_tvd(true_posterior_for_tvd, current_q_dist_dict)
                 history['tvd'].append(tvd)
                 if tvd < best_tvd:
                     best_tvd = tvd
@@ -361,7 +367,7 @@ class KSDVariationalInference:
                 log_msg = f"Epoch {epoch+1}/{num_epochs} | KSD: {loss_value:.6f}"
                 if scheduler is not None:
                     log_msg += f" | LR: {scheduler.get_last_lr()[0]:.6f}"
-                if true_posterior_for_tvd and not np.isnan(history['tvd'][-1]):
+                if true_posterior_for_tvd is not None and len(true_posterior_for_tvd) and not np.isnan(history['tvd'][-1]):
                     log_msg += f" | TVD: {history['tvd'][-1]:.6f}"
                 print(log_msg)
 

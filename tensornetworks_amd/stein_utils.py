@@ -62,6 +62,26 @@ def score_matrix(bn, x_dict, latent_vars_names, device=None, return_joint=False)
     return (S, pxz) if return_joint else S
 
 
+def true_posterior_table(bn, x_dict, latent_vars_names, device=None):
+    """Exact posterior P(z | x) for all 2^n latent outcomes at once, float64 [2^n] on the GPU (outcome index =
+    lexicographic tuple order, wire 0 the most significant bit), and P(x).  The array form of
+    BayesianNetwork.get_true_posterior (bayesian_network.py:148-253), whose dict of 2^n tuples does not scale
+    past n ~ 16; the joint p(x, z) comes from the same device kernel as the scores."""
+    _, pxz = score_matrix(bn, x_dict, latent_vars_names, device=device, return_joint=True)
+    p_obs = pxz.sum()
+    if float(p_obs) == 0.0:
+        print(f"Warning: P(Observed) is zero for evidence {x_dict}. Posterior is ill-defined.")
+        return torch.zeros_like(pxz), 0.0
+    return pxz / p_obs, float(p_obs)
+
+
+def tvd_table(p_true, p_approx):
+    """Total variation distance of two probability vectors on the device: 0.5 * sum |p - q| (utils.py:6-36 on arrays)."""
+    if p_true.shape != p_approx.shape:
+        raise ValueError("Probability arrays must have the same shape for simple TVD calculation.")
+    return 0.5 * (p_true.to(torch.float64) - p_approx.to(torch.float64)).abs().sum()
+
+
 def stein_gram_matrix(S, num_vars, length_scale=1.0):
     """Dense K_p [2^n, 2^n] float64 (replaces the 4^n calls of ksd_vi_quantum.py:125-141)."""
     return backend.stein_gram(S, num_vars, length_scale)

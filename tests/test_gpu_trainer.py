@@ -147,3 +147,32 @@ def test_full_size_step_n16(dev):
     loss_d, grad_d, _ = vi.ksd_and_grad()
     assert math.isclose(loss_k.item(), loss_d.item(), rel_tol=1e-9)
     np.testing.assert_allclose(grad_k.cpu().numpy(), grad_d.cpu().numpy(), rtol=1e-7, atol=1e-9 * grad_d.abs().max().item())
+
+
+def test_posterior_table_and_device_tvd(dev):
+    """exact posterior and TVD as arrays on the device == the reference's dict forms
+    (bayesian_network.py:148-253, utils.py:6-36), and train() tracks the same TVD with either."""
+    from tensornetworks_amd.stein_utils import true_posterior_table, tvd_table
+    from tensornetworks_amd.utils import calculate_tvd
+    bn = get_sprinkler_network(False)
+    lat, x = ['C', 'S', 'R'], {'W': 1}
+    post_dict, p_obs = bn.get_true_posterior(lat, x)
+    g = golden("sprinkler_w1.npz")
+    post_t, p_obs_t = true_posterior_table(bn, x, lat, device="cuda:0")
+    np.testing.assert_allclose(post_t.cpu().numpy(), np.array(list(post_dict.values())), rtol=1e-14)
+    np.testing.assert_allclose(post_t.cpu().numpy(), g["posterior"], rtol=1e-13)
+    assert abs(p_obs_t - p_obs) < 1e-15 and abs(post_t.sum().item() - 1) < 1e-14
+    bn6, lat6, obs6, x6 = synthetic_network(6, 3)
+    pd6, _ = bn6.get_true_posterior(lat6, x6)
+    pt6, _ = true_posterior_table(bn6, x6, lat6, device="cuda:0")
+    np.testing.assert_allclose(pt6.cpu().numpy(), np.array(list(pd6.values())), rtol=1e-13)
+    qv = torch.rand(64, dtype=torch.float64, device="cuda:0"); qv /= qv.sum()
+    qd = dict(zip(pd6.keys(), qv.cpu().tolist()))
+    assert abs(float(tvd_table(pt6, qv)) - calculate_tvd(pd6, qd)) < 1e-15
+    hists = []
+    for target in (post_dict, post_t):
+        vi = make_vi(bn, lat, ['W'], 3, 2, "hardware_efficient", "cuda:0", seed=3)
+        with contextlib.redirect_stdout(io.StringIO()):
+            hists.append(vi.train(x, 4, 0.05, verbose=True, true_posterior_for_tvd=target))
+    np.testing.assert_allclose(hists[0]['tvd'], hists[1]['tvd'], rtol=0, atol=1e-7)   # dict path prints float32-cast probs
+    np.testing.assert_array_equal(hists[0]['loss_ksd'], hists[1]['loss_ksd'])
