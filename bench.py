@@ -213,14 +213,26 @@ def main():
         circ_launches = n_passes * (2 if base_ms > 0 else 1)
         circ_kernel_ms = circ_ms + base_ms
         N = 1 << n
-        # algorithmic bytes: 32 * 2^n per gate per state; dense contraction 8 * 4^n
-        circ_bytes = 32.0 * N * n_gates * circuits_rank
+        # ALGORITHMIC bytes per launch = what the kernel's own algorithm has to move through HBM:
+        #   circuit pass: every state of the batch in (16 * 2^n; none in the first pass) and out (16 * 2^n, or
+        #                 8 * 2^n probabilities in the last pass); the SURVEY 8(d) UN-FUSED accounting (32 * 2^n per
+        #                 gate per state) is reported beside it as `survey_8d_unfused_equivalent_gbs`
+        #   contraction:  the upper triangle of K_p, 4 * 2^n * (2^n + 32) bytes per GPU share (SURVEY 8(d) counts the
+        #                 full matrix, 8 * 4^n: `survey_8d_full_matrix_gbs`), or the rank's rows for the row shard
+        unfused_bytes = 32.0 * N * n_gates * circuits_rank
+        circ_bytes = circuits_rank * (16.0 * N * (2 * n_passes - 2) + 8.0 * N) if n_passes > 1 else circuits_rank * 8.0 * N
         rows_rank = -(-N // world)
         sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
         stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
-        stein_bytes = 8.0 * N * rows_rank if gram_mode == "dense" else 16.0 * N * n * (n + 1)
-        # real HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.sh), recorded
-        # for the default workload only
+        full_bytes = 8.0 * N * rows_rank
+        if gram_mode != "dense":
+            stein_bytes = 16.0 * N * n * (n + 1)
+        elif sym:
+            stein_bytes = 4.0 * N * (N + 32) / world
+        else:
+            stein_bytes = full_bytes
+        # real HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.sh +
+        # tools/pmc_summarize.py), recorded for the default workload only
         pmc = {}
         pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic_n16_L6_dense.json")
         if args.workload == "n16_L6_dense" and world == 1 and not args.tile_bits and os.path.exists(pmc_file):
@@ -238,16 +250,19 @@ def main():
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_kernel_ms, 4),
                                     "avg_launch_ms": round(circ_kernel_ms / circ_launches, 4),
                                     "algorithmic_bytes_per_launch": circ_bytes / circ_launches, "traffic": t_circ,
-                                    "note": "achieved = SURVEY 8(d) un-fused accounting (32 * 2^n bytes per gate per state); the "
-                                            "fused engine keeps the state in LDS across a pass, so it exceeds the HBM peak; "
-                                            "traffic = measured HBM bytes per launch (PMC)"},
+                                    "survey_8d_unfused_equivalent_gbs": round(unfused_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
+                                    "note": "fused LDS-tiled engine: algorithmic bytes = each state read and written once per "
+                                            "pass; traffic = measured HBM bytes per launch (PMC); the same work as un-fused "
+                                            "gate-apply (SURVEY 8(d): 32 * 2^n bytes per gate per state) would need the "
+                                            "survey_8d_unfused_equivalent_gbs rate"},
             stein_name: {
                 "bound": "hbm", "launches_per_step": 1,
                 "achieved": round(stein_bytes / (stein_ms * 1e-3) / 1e9, 1) if stein_ms else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(stein_ms, 4),
                 "avg_launch_ms": round(stein_ms, 4), "algorithmic_bytes_per_launch": stein_bytes, "traffic": t_stein,
-                "note": ("achieved = SURVEY 8(d) accounting (8 * 4^n bytes); K_p is symmetric and only its upper triangle "
-                         "is read, so it exceeds the HBM peak; traffic = measured HBM bytes (PMC)") if sym else None},
+                "survey_8d_full_matrix_gbs": round(full_bytes / (stein_ms * 1e-3) / 1e9, 1) if (sym and stein_ms) else None,
+                "note": ("K_p is bitwise symmetric: only its upper triangle is read (algorithmic bytes = 4 * 2^n * (2^n + 32)); "
+                         "ms includes the column-partial reduce and the final sum; traffic = measured HBM bytes (PMC)") if sym else None},
         }
         for v in kern.values():
             v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
