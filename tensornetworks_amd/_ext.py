@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede loading the HIP library, see module do
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libbornvi_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("BORNVI_LIB") or os.path.join(_HERE, LIB_NAME)   # BORNVI_LIB: a tuning build of the same library
 
 BORNVI_OK = 0
 ANSATZ_IDS = {"hardware_efficient": 0, "all_to_all": 1, "basic": 2}

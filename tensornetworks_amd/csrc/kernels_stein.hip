@@ -478,6 +478,11 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 // Traffic: 8 * N^2 / 2 (+ one diagonal block per strip) + 2 * 8 * N^2 / (2 SYM_ROWS) bytes.
 // ------------------------------------------------------------------------------------------------
 constexpr int SYM_ROWS = 32;
+#ifndef BORNVI_SYM_RB
+#define BORNVI_SYM_RB 8
+#define BORNVI_SYM_CH 4
+#endif
+constexpr int SYM_RB = BORNVI_SYM_RB, SYM_CH = BORNVI_SYM_CH;   // wide loop: SYM_RB rows x SYM_CH 1-KiB chunks per row in flight
 constexpr int SYM_MAX_PARTS = 16;   // column pieces per strip (row-partial buffers in the workspace)
 
 __device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
@@ -512,38 +517,38 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr
     // triangle / diagonal chunks first with the general loop below, then the wide loop
     long long cw = cbeg > first_full ? cbeg : first_full;
     if (cw > cend) cw = cend;
-    const long long wide_end = cw + ((cend - cw) / 512) * 512;
+    const long long wide_end = cw + ((cend - cw) / (128 * SYM_CH)) * (128 * SYM_CH);
     // general loop over [cbeg, cw) happens below via `c`; the wide part [cw, wide_end) here
 #pragma unroll 1
-    for (long long cb = cw; cb < wide_end; cb += 512) {
-      double2 q4[4];
-      double z[4][2];
+    for (long long cb = cw; cb < wide_end; cb += 128 * SYM_CH) {
+      double2 q4[SYM_CH];
+      double z[SYM_CH][2];
 #pragma unroll
-      for (int u4 = 0; u4 < 4; ++u4) {
+      for (int u4 = 0; u4 < SYM_CH; ++u4) {
         q4[u4] = *reinterpret_cast<const double2*>(q + cb + u4 * 128 + lane * 2);
         z[u4][0] = 0.0; z[u4][1] = 0.0;
       }
 #pragma unroll
-      for (int r0 = 0; r0 < SYM_ROWS; r0 += 8) {
-        double2 kv[8][4];
+      for (int r0 = 0; r0 < SYM_ROWS; r0 += SYM_RB) {
+        double2 kv[SYM_RB][SYM_CH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < SYM_RB; ++u)
 #pragma unroll
-          for (int u4 = 0; u4 < 4; ++u4) {
+          for (int u4 = 0; u4 < SYM_CH; ++u4) {
             const double* p = Kr + (long long)(r0 + u) * N + cb + u4 * 128 + lane * 2;
             kv[u][u4].x = __builtin_nontemporal_load(p); kv[u][u4].y = __builtin_nontemporal_load(p + 1);
           }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < SYM_RB; ++u)
 #pragma unroll
-          for (int u4 = 0; u4 < 4; ++u4) {
+          for (int u4 = 0; u4 < SYM_CH; ++u4) {
             acc[r0 + u] = fma(kv[u][u4].x, q4[u4].x, fma(kv[u][u4].y, q4[u4].y, acc[r0 + u]));
             z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
             z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
           }
       }
 #pragma unroll
-      for (int u4 = 0; u4 < 4; ++u4)
+      for (int u4 = 0; u4 < SYM_CH; ++u4)
         *reinterpret_cast<double2*>(Zs + cb + u4 * 128 + lane * 2) = make_double2(z[u4][0], z[u4][1]);
     }
     // the general loop covers [cbeg, cw) and then [wide_end, cend)
