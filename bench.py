@@ -51,11 +51,11 @@ def gate_apply_microbench(dev, n=16, total_bytes=4 << 30, reps=20, warm=5):
     """Un-fused gate kernels on a batch of states >> Infinity Cache: algorithmic == real traffic,
     32 * 2^n bytes per gate per state."""
     from tensornetworks_amd import backend
-    from oracle import circuit as oc
     B = total_bytes // (16 << n)
     st = torch.randn((B, 2 << n), dtype=torch.float64, device=dev).view(torch.complex128).view(B, 1 << n)
     st /= st.abs().pow(2).sum(1, keepdim=True).sqrt()
-    U = oc.matrix_1q("RY", 0.3)
+    c, sn = np.cos(0.15), np.sin(0.15)                      # RY(0.3) = exp(-i 0.3 Y / 2)
+    U = np.array([[c, -sn], [sn, c]], dtype=np.complex128)
     out = {"n": n, "batch": int(B), "bytes_per_launch": int(32 * B << n), "gbs": {}}
     cases = [("ry_wire0", lambda: backend.gate1q_apply(st, n, 0, U)),
              (f"ry_wire{n // 2}", lambda: backend.gate1q_apply(st, n, n // 2, U)),
