@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--fast-path", type=int, default=-1, help="0: force the generic circuit kernel (A/B against the fast one)")
     ap.add_argument("--fast-wgs-per-cu", type=int, default=-1, help="fast circuit kernel: persistent workgroups per CU (0 = occupancy query)")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (e.g. low_bits=7), repeatable")
+    ap.add_argument("--host-sync", type=int, default=0, help="1: loss.item() after every step (reference epoch); 0: read the losses back after the K steps")
     ap.add_argument("--overlap", type=int, default=-1, help="1/0: contraction on a second stream beside the shifted circuits")
     args = ap.parse_args()
 
@@ -181,9 +182,13 @@ def main():
     total_steps = args.steps + args.warmup
     params, opt, sched = vi.make_optimizer(0.005, total_steps, True, "adam", (0.9, 0.999))
     clip = 10.0
+    # --host-sync 1: every step ends with loss.item() like the reference's epoch (the GPU idles while the host
+    # handles it); 0 (default): the same steps with the read-back of the K losses deferred to the end of the timed
+    # region (NaN/Inf guard on the device), so the K steps run back to back
+    step_fn = vi.training_step if args.host_sync else vi.training_step_async
     losses = []
     for _ in range(args.warmup):
-        losses.append(vi.training_step(params, opt, sched, clip)[0])
+        losses.append(step_fn(params, opt, sched, clip)[0])
 
     if world > 1:
         dist.barrier()
@@ -191,7 +196,7 @@ def main():
     vi.timers = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(vi.training_step(params, opt, sched, clip)[0])
+        losses.append(step_fn(params, opt, sched, clip)[0])
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -292,7 +297,8 @@ def main():
                          "note": "event spans; with the contraction on a second stream the 'circuits' and "
                                  "'base_circuit'+'stein' spans overlap in time" if base_ms > 0 else "event spans"},
             "precompute_seconds": round(precompute_s, 3),
-            "loss_first_last": [losses[0], losses[-1]],
+            "host_sync": "per step (loss.item())" if args.host_sync else "deferred: K steps back to back, losses read after the timed region",
+            "loss_first_last": [float(losses[0]), float(losses[-1])],
         }
         if world == 1 and not args.no_gate_bench:
             vi._K = None

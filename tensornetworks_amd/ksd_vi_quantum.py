@@ -281,6 +281,29 @@ class KSDVariationalInference:
                                                              eta_min=lr_born_machine / 10)
         return params, optimizer_born, scheduler
 
+    def training_step_async(self, params, optimizer_born, scheduler, gradient_clip_norm):
+        """The same epoch body with NO host synchronisation: returns (loss [1] float64 on the GPU, grad norm 0-dim
+        float32 on the GPU, q); the caller reads the values when it needs them (e.g. after K steps), so the GPU runs
+        the steps back to back instead of idling while the host handles `loss.item()`.  The NaN/Inf guard of the
+        reference (:147-148, "Skipping update") runs on the device: the fused optimiser kernel skips the update
+        when `found_inf` is set (the torch.amp.GradScaler mechanism of torch.optim).  One deviation: the LR
+        scheduler also advances on such a step (the host cannot know).  Needs theta and a fused optimiser on the GPU."""
+        theta = self.born_machine.theta
+        if not (theta.is_cuda and theta.dtype == torch.float32 and len(params) == 1 and optimizer_born.defaults.get("fused")):
+            raise backend.BornviError("training_step_async needs a float32 theta on the GPU and a fused torch optimiser")
+        optimizer_born.zero_grad()
+        loss_t, grad64, q = self.ksd_and_grad()
+        g32, grad_norm = backend.clip_cast_grad(grad64, gradient_clip_norm)
+        theta.grad = g32
+        optimizer_born.found_inf = torch.logical_not(torch.isfinite(loss_t)).to(torch.float32).reshape(())
+        try:
+            optimizer_born.step()
+        finally:
+            del optimizer_born.found_inf
+        if scheduler is not None:
+            scheduler.step()
+        return loss_t, grad_norm, q
+
     def training_step(self, params, optimizer_born, scheduler, gradient_clip_norm):
         """One epoch body (reference :111-161) without the logging: device step, NaN/Inf guard, clip,
         optimiser and scheduler step.  Returns (loss_value, grad_norm or None if skipped, q)."""

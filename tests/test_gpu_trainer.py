@@ -176,3 +176,45 @@ def test_posterior_table_and_device_tvd(dev):
             hists.append(vi.train(x, 4, 0.05, verbose=True, true_posterior_for_tvd=target))
     np.testing.assert_allclose(hists[0]['tvd'], hists[1]['tvd'], rtol=0, atol=1e-7)   # dict path prints float32-cast probs
     np.testing.assert_array_equal(hists[0]['loss_ksd'], hists[1]['loss_ksd'])
+
+
+def test_async_step_equals_sync_step_and_guards_on_device(dev):
+    """training_step_async (no host sync; NaN/Inf guard inside the fused optimiser kernel) walks the same
+    trajectory as training_step, and a non-finite loss leaves theta and the optimiser state untouched."""
+    bn = get_sprinkler_network(False)
+    x = {'W': 1}
+    runs = []
+    for use_async in (False, True):
+        vi = make_vi(bn, ['C', 'S', 'R'], ['W'], 3, 2, "hardware_efficient", "cuda:0", seed=11)
+        vi._prepare_stein(x, announce=False) if 'announce' in vi._prepare_stein.__code__.co_varnames else vi._prepare_stein(x)
+        params, opt, sched = vi.make_optimizer(0.05, 5, True, "adam", (0.9, 0.999))
+        losses, norms = [], []
+        for _ in range(5):
+            if use_async:
+                l, g, _ = vi.training_step_async(params, opt, sched, 10.0)
+            else:
+                l, g, _ = vi.training_step(params, opt, sched, 10.0)
+            losses.append(l); norms.append(g)
+        runs.append(([float(v) for v in losses], [float(v) for v in norms], vi.born_machine.theta.detach().cpu().numpy().copy(),
+                     sched.get_last_lr()[0]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    np.testing.assert_array_equal(runs[0][2], runs[1][2])
+    assert runs[0][3] == runs[1][3]
+    # device-side guard
+    vi = make_vi(bn, ['C', 'S', 'R'], ['W'], 3, 2, "hardware_efficient", "cuda:0", seed=11)
+    vi._prepare_stein(x)
+    params, opt, sched = vi.make_optimizer(0.05, 5, False, "adam", (0.9, 0.999))
+    vi.training_step_async(params, opt, sched, 10.0)
+    theta_before = vi.born_machine.theta.detach().clone()
+    state_before = {k: v.clone() for k, v in opt.state[params[0]].items() if torch.is_tensor(v)}
+    real = vi.ksd_and_grad
+
+    def poisoned():
+        loss, grad, q = real()
+        return loss * float("inf"), grad, q
+    vi.ksd_and_grad = poisoned
+    l, _, _ = vi.training_step_async(params, opt, sched, 10.0)
+    assert not np.isfinite(float(l))
+    assert torch.equal(vi.born_machine.theta.detach(), theta_before)
+    for k, v in state_before.items():
+        assert torch.equal(opt.state[params[0]][k], v), k
