@@ -742,18 +742,40 @@ __global__ __launch_bounds__(256) void born_probs_kernel(const double2* __restri
 // grad[p] = scale * sum_z w[z] (q+[z] - q-[z]);  rows (+p, -p) of `shifted`; one workgroup per p.
 // scale = 1/2 (ksd2 == nullptr) or 1/2 / sqrt(max(ksd2, 1e-12)) with the clamp's zero gradient
 // below 1e-12 (ksd_vi_quantum.py:145).  Fixed-order tree reduction: deterministic.
-__global__ __launch_bounds__(256) void shift_dot_kernel(const double* __restrict__ shifted, const double* __restrict__ w,
-                                                        const double* __restrict__ ksd2, long long N,
-                                                        double* __restrict__ grad, double* __restrict__ loss_out) {
-  __shared__ double red[256];
+constexpr int SHIFT_DOT_THREADS = 1024;
+__global__ __launch_bounds__(SHIFT_DOT_THREADS) void shift_dot_kernel(const double* __restrict__ shifted, const double* __restrict__ w,
+                                                                     const double* __restrict__ ksd2, long long N,
+                                                                     double* __restrict__ grad, double* __restrict__ loss_out) {
+  __shared__ double red[SHIFT_DOT_THREADS];
   const long long p = blockIdx.x;
   const double* qp = shifted + (2 * p) * N;
   const double* qm = qp + N;
   double acc = 0.0;
-  for (long long z = threadIdx.x; z < N; z += blockDim.x) acc += w[z] * (qp[z] - qm[z]);
+  if ((N & 1) == 0) {
+    // 16-byte loads, four pairs in flight per thread: one workgroup (16 waves) per parameter streams its two
+    // probability vectors at the CU's full rate
+    const long long N2 = N >> 1;
+    const double2* __restrict__ qp2 = reinterpret_cast<const double2*>(qp);
+    const double2* __restrict__ qm2 = reinterpret_cast<const double2*>(qm);
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    long long z = threadIdx.x;
+    for (; z + 3 * SHIFT_DOT_THREADS < N2; z += 4 * SHIFT_DOT_THREADS) {
+      double2 a[4], b[4], c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = qp2[z + u * SHIFT_DOT_THREADS]; b[u] = qm2[z + u * SHIFT_DOT_THREADS]; c[u] = w2[z + u * SHIFT_DOT_THREADS]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += c[u].x * (a[u].x - b[u].x) + c[u].y * (a[u].y - b[u].y);
+    }
+    for (; z < N2; z += SHIFT_DOT_THREADS) {
+      const double2 a = qp2[z], b = qm2[z], c = w2[z];
+      acc += c.x * (a.x - b.x) + c.y * (a.y - b.y);
+    }
+  } else {
+    for (long long z = threadIdx.x; z < N; z += SHIFT_DOT_THREADS) acc += w[z] * (qp[z] - qm[z]);
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = SHIFT_DOT_THREADS / 2; s > 0; s >>= 1) {      // fixed-order tree: deterministic
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -910,7 +932,7 @@ hipError_t launch_born_probs(const double* state, double* probs, int n, long lon
 hipError_t launch_shift_dot(const double* shifted, int n_shift, const double* w, const double* ksd2, int n,
                             double* grad, double* loss_out, hipStream_t st) {
   if (n_shift <= 0) return hipSuccess;
-  shift_dot_kernel<<<n_shift, 256, 0, st>>>(shifted, w, ksd2, 1ll << n, grad, loss_out);
+  shift_dot_kernel<<<n_shift, SHIFT_DOT_THREADS, 0, st>>>(shifted, w, ksd2, 1ll << n, grad, loss_out);
   return hipGetLastError();
 }
 
