@@ -26,7 +26,7 @@ def be(dev):
     from tensornetworks_amd import backend
     yield backend
     backend.set_option(dev, "tile_bits", 13)          # restore the planner defaults
-    backend.set_option(dev, "tile_bits_multi", 12)
+    backend.set_option(dev, "tile_bits_multi", 0)     # (0 = automatic: 2^11 tiles up to n = 16, 2^12 above)
 
 
 def gpu_probs(be, dev, ansatz, n, L, thetas):
@@ -213,3 +213,23 @@ def test_n20_circuit_and_kron_matvec(be, dev):
     scale = np.abs(y_o).max()
     np.testing.assert_allclose(y.cpu().numpy(), y_o, rtol=0, atol=1e-10 * scale)
     assert abs(k2.item() - float(q[0] @ y_o)) <= 1e-9 * abs(float(q[0] @ y_o))
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+def test_persistent_tile_loop(be, dev, ansatz):
+    """More tiles than co-resident workgroups: every workgroup of the fast pass kernel walks over several tiles
+    (next-tile prefetch in flight, hand-counted vmcnt waits, stage tables kept in LDS).  All circuits of the batch
+    use one of two parameter vectors, so every output row must equal the oracle's row for its parameters."""
+    n, L, kb = 14, 2, 11
+    be.set_option(dev, "tile_bits", kb)
+    be.set_option(dev, "fast_workgroups_per_cu", 1)        # 256 workgroups for 100 x 8 tiles
+    try:
+        rng = np.random.default_rng(5)
+        th2 = rng.uniform(-np.pi, np.pi, (2, oc.num_params(ansatz, n, L)))
+        pick = rng.integers(0, 2, 100)
+        q = gpu_probs(be, dev, ansatz, n, L, th2[pick])
+        ref = [oc.probs(ansatz, n, L, th2[0]), oc.probs(ansatz, n, L, th2[1])]
+        for b in range(100):
+            np.testing.assert_allclose(q[b], ref[pick[b]], rtol=RTOL, atol=ATOL)
+    finally:
+        be.set_option(dev, "fast_workgroups_per_cu", 0)
