@@ -46,6 +46,8 @@ struct bornvi_ctx {
   int wgs_per_cu = 0;   // generic kernel: > 0 = persistent grid of num_cus * wgs_per_cu workgroups; 0 = one per tile
   int fast_path = 1;    // 1: circuit_pass_fast_kernel where the plan is eligible; 0: always the generic kernel
   int fast_wgs_per_cu = 0;  // fast kernel: 0 = what the occupancy query admits
+  int direct_stages = 3;    // fast kernel: bit 0 / 1 = first / last stage of a pass straight from / to HBM where the plan allows
+                            // (A/B switch; bits 2.. = 1 + the only pass allowed to, for debugging)
 };
 
 namespace {
@@ -80,10 +82,10 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
   }
   // fast path only when the tile, the matrices and one tile row of the stage tables fit the CU's 160 KiB of LDS
   if (build_fast_tables(dp->plan, FAST_TABLE_MAX_BYTES, dp->fast) &&
-      dp->plan.fast_lds_bytes(dp->fast.any_sign) <= MAX_LDS_BYTES) {
+      dp->plan.fast_lds_bytes(dp->fast.max_tab_rows) <= MAX_LDS_BYTES) {
     HIPCHK(h, hipMalloc((void**)&dp->d_fast, dp->fast.words.size() * sizeof(uint32_t)));
     HIPCHK(h, hipMemcpy(dp->d_fast, dp->fast.words.data(), dp->fast.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    const size_t flds = dp->plan.fast_lds_bytes(dp->fast.any_sign);
+    const size_t flds = dp->plan.fast_lds_bytes(dp->fast.max_tab_rows);
     if (flds > h->max_lds_prepared) {
       HIPCHK(h, prepare_circuit_kernel(flds));
       h->max_lds_prepared = flds;
@@ -122,8 +124,10 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
     if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
       const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * h->num_cus : dp->fast_workgroups;
       HIPCHK(h, launch_circuit_pass_fast(dp->d_words, p.pass_off[i], dp->d_fast, dp->fast.pass_off[i], p.n, p.k,
-                                         p.fast_lds_bytes(dp->fast.any_sign), bc, in, out, final_probs, gates, gate_stride, wgs,
-                                         p.fast_lds_tab_off(), h->debug_flags, st));
+                                         p.fast_lds_bytes(dp->fast.max_tab_rows), bc, in, out, final_probs, gates, gate_stride, wgs,
+                                         p.fast_lds_tab_off(), p.fast_lds_mats2_off(dp->fast.max_tab_rows),
+                                         ((h->direct_stages >> 2) && (h->direct_stages >> 2) - 1 != i) ? 0 : (h->direct_stages & 3),
+                                         h->debug_flags, st));
     } else {
       HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, p.lds_bytes(), bc, in, out, final_probs, gates, gate_stride, h->wgs_per_cu * h->num_cus, h->debug_flags, st));
     }
@@ -214,6 +218,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
     return BORNVI_OK;
   }
   if (!std::strcmp(name, "fast_path")) { h->fast_path = value ? 1 : 0; return BORNVI_OK; }
+  if (!std::strcmp(name, "direct_stages")) { h->direct_stages = (int)value; return BORNVI_OK; }   // bits 2..: 1 + the only pass allowed (debug)
   if (!std::strcmp(name, "fast_workgroups_per_cu")) {
     if (value < 0 || value > 16) return fail(h, BORNVI_ERR_INVALID, "option value out of range");
     h->fast_wgs_per_cu = (int)value;

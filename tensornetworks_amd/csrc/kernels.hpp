@@ -20,7 +20,7 @@ int circuit_fast_workgroups_per_cu(int threads, size_t lds);
 hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, const uint32_t* fast, uint32_t fast_off,
                                     int n, int k, size_t lds, int batch, const void* in, void* out, double* probs,
                                     const double* gates, long long gate_stride, int max_workgroups, size_t lds_tab_off,
-                                    int dbg, hipStream_t st);
+                                    size_t lds_mats2_off, int direct_mask, int dbg, hipStream_t st);
 hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st);
 hipError_t launch_cnot(double* state, int n, long long batch, int control, int target, hipStream_t st);
 hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st);

@@ -445,27 +445,53 @@ __device__ __forceinline__ void apply_sign_bits(uint32_t m, double (&ar)[16], do
   }
 }
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Vector memory ops the COMPILER does not track (it would otherwise drain vmcnt to 0 at every loop merge, i.e.
+// wait for the previous tile's stores and for the next tile's loads in the middle of the pipeline).  The kernel
+// waits by hand: s_waitcnt vmcnt(N) = all but the wave's N youngest vector-memory ops are done, loads and
+// stores counted together in issue order (MI355X_MICROARCH.md, cycle constants).
+// The destination is a READ-WRITE operand ("+v"): the load lands in the very register that already carries the
+// loop-carried variable.  As a plain output ("=v") the compiler may give the asm a fresh register and COPY it into
+// the variable's register right behind the asm statement -- i.e. before the data has arrived (seen on gfx950: the
+// second tile of every workgroup was computed from stale registers).
+__device__ __forceinline__ void async_load16(d2_t& dst, uint32_t byte_off, const void* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+// (the s_nop covers the "VMEM store of more than 64 bits, then VALU write of its data registers" hazard: the
+// compiler pads its own stores but does not look inside inline asm, and it reuses the data registers at once)
+__device__ __forceinline__ void async_store16(uint32_t byte_off, d2_t val, void* base) {
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+}
+__device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void* base) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+}
+
 // One stage on the 16 amplitudes a thread owns, specialised on the number of fused gates (the planner puts
 // them on register bits 0 .. NG-1) and on the two CZ sign products: straight-line code, no merges of the
 // 64 amplitude registers (conditional gates cost ~100 register copies per stage in the generic kernel).
-template <int NG, bool PRE, bool POST, bool DEBUG>
+// IO: 0 = LDS -> LDS;  1 = the amplitudes are the prefetched registers `v` (first stage of a pass: no tile
+// fill, no LDS read);  2 = the results go straight to HBM (last stage: no LDS write, no tile drain): 16 stores
+// at  hbm_off ^ (xor of hbm_basis over the bits of the slot number), |amp|^2 as 8 bytes when `fin`.
+template <int NG, bool PRE, bool POST, int IO, bool DEBUG>
 __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const double2* __restrict__ Us, uint32_t my_rw,
-                                           uint32_t my_sg, const uint32_t (&G)[10], int dbg) {
+                                           uint32_t my_sg, const uint32_t (&G)[10], int dbg, d2_t (&v)[16],
+                                           uint32_t hbm_off, const uint32_t (&hbm_basis)[4], void* hbm_base, bool fin) {
   double ar[16], ai[16];
-  {
-    uint32_t ra[16];   // byte addresses of the 16 slots: GF(2)-linear in the slot number
-    ra[0] = (my_rw & 0xffffu) << 4;
+  if (IO == 1) {
 #pragma unroll
-    for (int j = 1; j < 16; ++j) {
-      const int low = j & (-j), bit = (low == 1) ? 0 : (low == 2) ? 1 : (low == 4) ? 2 : 3;
-      ra[j] = ra[j ^ low] ^ G[FS_RB + bit];
-    }
+    for (int j = 0; j < 16; ++j) { ar[j] = v[j].x; ai[j] = v[j].y; }
+  } else {
+    // byte addresses of the 16 slots: GF(2)-linear in the slot number -- one per-thread base, the 16 offsets are
+    // wave-uniform (scalar registers), one v_xor per access and no address kept live across the gates
+    const uint32_t ra0 = (my_rw & 0xffffu) << 4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+      const uint32_t ra = ra0 ^ (((j & 1) ? G[FS_RB] : 0u) ^ ((j & 2) ? G[FS_RB + 1] : 0u) ^ ((j & 4) ? G[FS_RB + 2] : 0u) ^ ((j & 8) ? G[FS_RB + 3] : 0u));
       if (!(DEBUG && (dbg & 2))) {
-        const double2 x = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tile) + ra[j]);
+        const double2 x = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tile) + ra);
         ar[j] = x.x; ai[j] = x.y;
-      } else { ar[j] = (double)(ra[j] + j); ai[j] = 0.0; }
+      } else { ar[j] = (double)(ra + j); ai[j] = 0.0; }
     }
   }
   if (PRE) apply_sign_bits(my_sg & 0xffffu, ar, ai);
@@ -477,17 +503,24 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
     if (NG > 3) { load_u(Us + 12, U); op_u1_inplace<3>(ar, ai, U); }
   }
   if (POST) apply_sign_bits(my_sg >> 16, ar, ai);
-  {
-    uint32_t wa[16];
-    wa[0] = (my_rw >> 16) << 4;
+  if (IO == 2) {
+    uint32_t ha0 = hbm_off;
+    asm volatile("" : "+v"(ha0));     // addresses are formed here, after the gates
 #pragma unroll
-    for (int j = 1; j < 16; ++j) {
-      const int low = j & (-j), bit = (low == 1) ? 0 : (low == 2) ? 1 : (low == 4) ? 2 : 3;
-      wa[j] = wa[j ^ low] ^ G[FS_WB + bit];
+    for (int j = 0; j < 16; ++j) {
+      if (DEBUG && (dbg & 8)) continue;
+      const uint32_t ha = ha0 ^ (((j & 1) ? hbm_basis[0] : 0u) ^ ((j & 2) ? hbm_basis[1] : 0u) ^ ((j & 4) ? hbm_basis[2] : 0u) ^ ((j & 8) ? hbm_basis[3] : 0u));
+      if (fin) async_store8(ha, ar[j] * ar[j] + ai[j] * ai[j], hbm_base);
+      else async_store16(ha, (d2_t){ar[j], ai[j]}, hbm_base);
     }
+  } else {
+    uint32_t wa0 = (my_rw >> 16) << 4;
+    asm volatile("" : "+v"(wa0));     // addresses are formed here, after the gates
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (!(DEBUG && (dbg & 2))) *reinterpret_cast<double2*>(reinterpret_cast<char*>(tile) + wa[j]) = make_double2(ar[j], ai[j]);
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t wa = wa0 ^ (((j & 1) ? G[FS_WB] : 0u) ^ ((j & 2) ? G[FS_WB + 1] : 0u) ^ ((j & 4) ? G[FS_WB + 2] : 0u) ^ ((j & 8) ? G[FS_WB + 3] : 0u));
+      if (!(DEBUG && (dbg & 2))) *reinterpret_cast<double2*>(reinterpret_cast<char*>(tile) + wa) = make_double2(ar[j], ai[j]);
+    }
   }
   if (DEBUG && (dbg & 2)) {
     double acc = 0.0;
@@ -497,20 +530,26 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
   }
 }
 
-typedef double d2_t __attribute__((ext_vector_type(2)));
-
-// Vector memory ops the COMPILER does not track (it would otherwise drain vmcnt to 0 at every loop merge, i.e.
-// wait for the previous tile's stores and for the next tile's loads in the middle of the pipeline).  The kernel
-// waits by hand: s_waitcnt vmcnt(N) = all but the wave's N youngest vector-memory ops are done, loads and
-// stores counted together in issue order (MI355X_MICROARCH.md, cycle constants).
-__device__ __forceinline__ void async_load16(d2_t& dst, uint32_t byte_off, const void* base) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
-}
-__device__ __forceinline__ void async_store16(uint32_t byte_off, d2_t val, void* base) {
-  asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
-}
-__device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void* base) {
-  asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+// all (gate count, pre sign, post sign) kinds of one IO mode behind one scalar switch
+template <int IO, bool DEBUG>
+__device__ __forceinline__ void stage_dispatch(uint32_t kind, double2* __restrict__ tile, const double2* __restrict__ Us,
+                                               uint32_t my_rw, uint32_t my_sg, const uint32_t (&G)[10], int dbg,
+                                               d2_t (&v)[16], uint32_t hbm_off, const uint32_t (&hbm_basis)[4],
+                                               void* hbm_base, bool fin) {
+#define BORNVI_STAGE(NG, PRE, POST) \
+  case (NG) | ((PRE) << 3) | ((POST) << 4): \
+    stage_body<NG, PRE, POST, IO, DEBUG>(tile, Us, my_rw, my_sg, G, dbg, v, hbm_off, hbm_basis, hbm_base, fin); break;
+#define BORNVI_STAGE_NG(PRE, POST) \
+  BORNVI_STAGE(0, PRE, POST) BORNVI_STAGE(1, PRE, POST) BORNVI_STAGE(2, PRE, POST) BORNVI_STAGE(3, PRE, POST) BORNVI_STAGE(4, PRE, POST)
+  switch (kind) {
+    BORNVI_STAGE_NG(0, 0)
+    BORNVI_STAGE_NG(1, 0)
+    BORNVI_STAGE_NG(0, 1)
+    BORNVI_STAGE_NG(1, 1)
+    default: break;
+  }
+#undef BORNVI_STAGE_NG
+#undef BORNVI_STAGE
 }
 
 template <bool DEBUG>
@@ -518,7 +557,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const uint32_t* __restrict__ fast, uint32_t fast_off,
     const double2* __restrict__ in, double2* __restrict__ out, double* __restrict__ probs,
     const double* __restrict__ gates, long long gate_stride, long long state_stride, long long total_tiles,
-    uint32_t lds_tab_off /* double2 units */, int dbg_arg) {
+    uint32_t lds_tab_off /* double2 units */, uint32_t lds_mats2_off /* double2 units */, int direct_mask, int dbg_arg) {
   const int dbg = DEBUG ? dbg_arg : 0;
   extern __shared__ double2 tile[];
   const uint32_t* __restrict__ P = plan + pass_off;
@@ -550,15 +589,13 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
   const uint32_t stage_words = 1u << (n - 4);     // table words per stage
   double2* __restrict__ mats = tile + ksize;      // [nstages][4 register bits][4 double2]
   uint32_t* __restrict__ tab_rw = reinterpret_cast<uint32_t*>(tile + lds_tab_off);   // [nstages][T] of this tile row
-  uint32_t* __restrict__ tab_sg = tab_rw + (uint32_t)nstages * T;
+  uint32_t* __restrict__ tab_sg = tab_rw + (uint32_t)nstages * T;    // rows of the sign stages only, in stage order
   const bool init = flags & PASS_INIT, fin = flags & PASS_FINAL;
 
-  // ---- per-thread constants of the tile <-> HBM maps (the tile-index parts are wave-uniform, per tile) ----
-  const uint32_t thr_in = ((t & ((1u << lo_in) - 1u)) | deposit16(t, lo_in, kt, in_phys)) << 4;      // bytes
-  const uint32_t slot_in = xor_map16(t, kt, in_mask);
-  const uint32_t slot_out = xor_map16(t, kt, out_mask);
+  // ---- the tile <-> HBM maps: the thread parts (thr_in, slot_in, slot_out, thr_out below) are recomputed from the
+  // thread id where they are used -- a dozen VALU ops per tile; kept in registers across the tile loop they were
+  // spilled, and every scratch reload drains vmcnt, i.e. waits for the prefetch in flight ----
   const int out_shift = fin ? 3 : 4;   // bytes per element written
-  const uint32_t thr_out = xor_cols(t, kt, P + PW_OUT_COL) << out_shift;   // phys-out address: GF(2)-linear (PW_OUT_COL)
   uint32_t ipos[4], imask[4], lpos[4], pcol[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -567,131 +604,184 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     lpos[m] = half16_dyn(out_mask, kt + m);
     pcol[m] = P[PW_OUT_COL + kt + m] << out_shift;
   }
-  // the (at most two) 16-byte pieces of the pass's matrices this thread stages per tile
-  int mat_off[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint32_t piece = t + (uint32_t)c * T;
-    mat_off[c] = -1;
-    if (piece < (uint32_t)nstages * 16u) {
-      const uint32_t sm = piece >> 2;
+  // the 16-byte piece of the pass's matrices this thread stages per tile (the planner admits at most T pieces);
+  // a slot without a gate copies a piece of fused gate 0: never read, and no per-thread predicate to keep.
+  // Per-thread words that must survive the tile loop live in LDS (tw_*): kept in registers they were spilled, and
+  // a scratch reload drains vmcnt -- it waits for the prefetch in flight and for the last tile's store acks.
+  const uint32_t npieces = (uint32_t)nstages * 16u;
+  const uint32_t sign_any = sign_pre | sign_post;
+  uint32_t* __restrict__ tw_mat = tab_sg + (uint32_t)__popc(sign_any) * T;   // byte offset of the piece in the gate array
+  uint32_t* __restrict__ tw_slots = tw_mat + T;  // thread part of the tile-fill slot | of the tile-drain slot << 16
+  uint32_t* __restrict__ tw_in = tw_slots + T;   // byte offset of the thread's first load: phys-in thread part, or (direct
+                                                 // first stage) of slot 0 of its first-stage group for tile row g_pref
+  uint32_t* __restrict__ tw_out = tw_in + T;     // same on the way out (thread part of phys-out | last-stage group, row g_tab)
+  {
+    uint32_t mo = 0;
+    if (t < npieces) {
+      const uint32_t sm = t >> 2;
       const uint32_t w = P[PW_MATS + (sm >> 1)];
       const uint32_t f = (sm & 1u) ? (w >> 16) : (w & 0xffffu);
-      if (f != 0xffffu) mat_off[c] = (int)((f * 4u + (piece & 3u)) << 4);   // bytes
+      mo = ((f != 0xffffu ? f : 0u) * 4u + (t & 3u)) << 4;
     }
+    tw_mat[t] = mo;
   }
+  // ---- direct HBM <-> register stages (plan.hpp: FH_IN_TAB / FH_OUT_TAB) ----
+  const uint32_t in_tab = F[FH_IN_TAB], out_tab = F[FH_OUT_TAB];
+  // (direct_mask: bit 0 / 1 allow the direct first / last stage -- an A/B switch, bornvi_set_option "direct_stages")
+  const bool direct_in = in_tab != 0 && !init && nstages > 0 && (direct_mask & 1);     // first stage: amplitudes straight from HBM
+  const bool direct_out = out_tab != 0 && nstages > 1 && (direct_mask & 2);   // last stage (not also the first): results straight to HBM
+  const uint32_t in_basis[4] = {F[FH_IN_BASIS], F[FH_IN_BASIS + 1], F[FH_IN_BASIS + 2], F[FH_IN_BASIS + 3]};
+  const uint32_t out_basis[4] = {F[FH_OUT_BASIS], F[FH_OUT_BASIS + 1], F[FH_OUT_BASIS + 2], F[FH_OUT_BASIS + 3]};
+  // byte offsets xor-ed into a thread's base offset for the 16 elements it loads (bits of the element number)
+  const uint32_t in_step[4] = {direct_in ? in_basis[0] : 16u << ipos[0], direct_in ? in_basis[1] : 16u << ipos[1],
+                               direct_in ? in_basis[2] : 16u << ipos[2], direct_in ? in_basis[3] : 16u << ipos[3]};
+  // thread parts of the ordinary tile <-> HBM maps, computed once per workgroup and parked in LDS (recomputed per
+  // tile they cost ~500 VALU instructions per wave and tile; kept in registers they were spilled)
+  tw_slots[t] = xor_map16(t, kt, in_mask) | (xor_map16(t, kt, out_mask) << 16);
+  if (!direct_in) tw_in[t] = ((t & ((1u << lo_in) - 1u)) | deposit16(t, lo_in, kt, in_phys)) << 4;
+  if (!direct_out) tw_out[t] = xor_cols(t, kt, P + PW_OUT_COL) << out_shift;      // phys-out address: GF(2)-linear (PW_OUT_COL)
+  double2* __restrict__ mats_b = tile + lds_mats2_off;   // second matrix buffer: the NEXT tile's matrices land here
 
   d2_t v[MAX_TILE_ITERS];   // amplitudes of the NEXT tile (in flight during the current tile's stages)
-  d2_t mp[2];               // its matrices
+  d2_t mp;                  // its piece of the matrices
 #pragma unroll
   for (int i = 0; i < MAX_TILE_ITERS; ++i) v[i] = (d2_t){0.0, 0.0};
-  mp[0] = mp[1] = (d2_t){0.0, 0.0};
+  mp = (d2_t){0.0, 0.0};
+  uint32_t g_pref = 0xffffffffu;   // tile row whose first-stage offsets are in tw_in (direct_in)
 #define BORNVI_PREFETCH(Tn)                                                                          \
   do {                                                                                               \
     const uint32_t gn_ = (uint32_t)((Tn) & ((1ll << gbits) - 1));                                    \
     const long long bn_ = (Tn) >> gbits;                                                             \
     const double* gsrc_ = gates + bn_ * gate_stride;                                                 \
-    if (mat_off[0] >= 0) async_load16(mp[0], (uint32_t)mat_off[0], gsrc_);                           \
-    if (mat_off[1] >= 0) async_load16(mp[1], (uint32_t)mat_off[1], gsrc_);                           \
+    uint32_t tt_ = t;                                                                                \
+    asm volatile("" : "+v"(tt_));   /* (nothing derived from the thread id is hoisted out of the loop) */ \
+    if (direct_in && gn_ != g_pref) {   /* rare: compiler-tracked load, waited for inside this branch */ \
+      g_pref = gn_;                                                                                  \
+      tw_in[tt_] = fast[in_tab + (gn_ << kt) + tt_];                                                 \
+    }                                                                                                \
+    if (tt_ < npieces) async_load16(mp, tw_mat[tt_], gsrc_);                                         \
     if (!init && !(dbg & 4)) {                                                                       \
-      const double2* src_ = in + bn_ * state_stride + deposit16(gn_, 0, gbits, in_gphys);            \
-      _Pragma("unroll") for (int i = 0; i < MAX_TILE_ITERS; ++i) {                                   \
-        const uint32_t itp_ = ((i & 1) ? 16u << ipos[0] : 0u) | ((i & 2) ? 16u << ipos[1] : 0u) |    \
-                              ((i & 4) ? 16u << ipos[2] : 0u) | ((i & 8) ? 16u << ipos[3] : 0u);     \
-        async_load16(v[i], thr_in | itp_, src_);                                                     \
-      }                                                                                              \
+      /* one per-thread base offset, 16 wave-uniform offsets xor-ed in (both maps are bitwise disjoint or   \
+         GF(2)-linear); the empty asm keeps the 16 sums from being hoisted out of the tile loop and spilled */ \
+      const uint32_t base_ = tw_in[tt_];                                                             \
+      const double2* src_ = in + bn_ * state_stride + (direct_in ? 0u : deposit16(gn_, 0, gbits, in_gphys)); \
+      _Pragma("unroll") for (int i = 0; i < MAX_TILE_ITERS; ++i)                                     \
+        async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^      \
+                                    ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
     }                                                                                                \
   } while (0)
 
-  long long Tcur = blockIdx.x;
-  if (Tcur < total_tiles) BORNVI_PREFETCH(Tcur);
+  // ---- the tile loop.  There is exactly ONE expansion of the prefetch in the kernel, inside the loop: trip -1 only
+  // starts the pipeline (loads the first tile and its matrices), every later trip consumes the tile in flight, issues
+  // the loads of the next one and works on its own.  With a second load site (a prologue) the compiler has to merge
+  // two definitions of the in-flight registers at the loop header and may do it with register copies placed right
+  // behind a load -- copies of registers whose data has not arrived (tools/check_async_regs.py looks for that).
   uint32_t g_tab = 0xffffffffu;   // tile row whose stage tables are in LDS
-  bool first = true;
-  for (; Tcur < total_tiles; Tcur += gridDim.x) {
-    const uint32_t g = (uint32_t)(Tcur & ((1ll << gbits) - 1));
-    const long long b = Tcur >> gbits;
-    // ---- stage tables of this tile row -> LDS.  The launcher makes the grid a multiple of the tiles per
-    // state whenever it can, so a workgroup keeps its row and this runs once (it drains vmcnt: these are
-    // compiler-tracked loads) ----
-    if (g != g_tab) {
-      g_tab = g;
-      const uint32_t row = (g << kt) + t;
-      for (int s = 0; s < nstages; ++s) {
-        tab_rw[(uint32_t)s * T + t] = fast[rw_base + (uint32_t)s * stage_words + row];
-        if (any_sign) tab_sg[(uint32_t)s * T + t] = fast[sg_base + (uint32_t)s * stage_words + row];
+  uint32_t parity = 1;            // matrix buffer of the current tile (trip -1 stages tile 0's matrices into buffer 0)
+  const uint32_t* __restrict__ FS0 = F + FH_WORDS;
+#define BORNVI_RUN_STAGE(S_, IO_)                                                                               \
+  do {                                                                                                          \
+    const uint32_t* __restrict__ FS_ = FS0 + (S_) * FS_WORDS;                                                   \
+    uint32_t G_[10];                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) G_[i_] = FS_[i_];                                         \
+    const uint32_t kind_ = FS_[FS_KIND];   /* fused gates (register bits 0 .. ng-1) | pre sign << 3 | post sign << 4 */ \
+    const uint32_t rw_ = tab_rw[(uint32_t)(S_) * T + t];                                                        \
+    const uint32_t sg_ = (kind_ >> 3) ? tab_sg[(uint32_t)__popc(sign_any & ((1u << (S_)) - 1u)) * T + t] : 0u;  \
+    stage_dispatch<IO_, DEBUG>(kind_, tile, mats + (S_) * 16, rw_, sg_, G_, dbg, v, (IO_) == 2 ? tw_out[t] : 0u, \
+                               out_basis, hbm_base, fin);                                                       \
+  } while (0)
+  for (long long Tcur = (long long)blockIdx.x - (long long)gridDim.x;; Tcur += gridDim.x, parity ^= 1u) {
+    const bool real = Tcur >= 0;
+    const long long Tnext = Tcur + gridDim.x;
+    const bool has_next = Tnext < total_tiles;
+    if (!real && !has_next) break;
+    const uint32_t g = real ? (uint32_t)(Tcur & ((1ll << gbits) - 1)) : 0u;
+    const long long b = real ? (Tcur >> gbits) : 0;
+    double2* __restrict__ mats = parity ? mats_b : tile + ksize;         // this tile's matrices
+    double2* __restrict__ mats_next = parity ? tile + ksize : mats_b;
+    double2* dst = out + b * state_stride;
+    double* pdst = probs + (b << n);
+    void* hbm_base = fin ? (void*)pdst : (void*)dst;
+    if (real) {
+      // ---- the tile has arrived in registers: all but this wave's 16 tile-out stores are done (after trip -1
+      // nothing is outstanding) ----
+      if (DEBUG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MAX_TILE_ITERS; ++i) asm volatile("" : "+v"(v[i]));
+      // ---- registers -> LDS: the tile (head CNOTs of the pass folded into the slot), unless the first stage
+      // takes the registers as they are ----
+      if (init) {
+        for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
+      } else if (!direct_in && !(dbg & 4)) {
+        const uint32_t slot_t = (tw_slots[t] & 0xffffu) ^ xor_map16(g, gbits, in_gmask);
+#pragma unroll
+        for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+          const uint32_t its = ((i & 1) ? imask[0] : 0u) ^ ((i & 2) ? imask[1] : 0u) ^ ((i & 4) ? imask[2] : 0u) ^ ((i & 8) ? imask[3] : 0u);
+          tile[slot_t ^ its] = make_double2(v[i].x, v[i].y);
+        }
+      }
+      if (direct_in) BORNVI_RUN_STAGE(0, 1);    // (the matrices were staged a trip ago)
+      asm volatile("" ::: "memory");
+    }
+    // ---- the registers are free: the next tile starts its trip from HBM now (the only load site) ----
+    if (has_next) BORNVI_PREFETCH(Tnext);
+    if (real) {
+      __syncthreads();                          // the tile (or the first stage's result) is in LDS
+      for (int s = direct_in ? 1 : 0; s < nstages; ++s) {
+        if (s == nstages - 1 && direct_out) {
+          BORNVI_RUN_STAGE(s, 2);
+        } else {
+          BORNVI_RUN_STAGE(s, 0);
+          __syncthreads();
+        }
+      }
+      // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
+      // vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
+      if (!direct_out) {
+        const uint32_t gout = xor_cols(g, gbits, P + PW_OUT_GCOL) << out_shift;
+        const uint32_t thr_l = (tw_slots[t] >> 16) ^ xor_map16(g, gbits, out_gmask);   // tail CNOTs folded in
+        const uint32_t thr_out = tw_out[t];
+#pragma unroll
+        for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+          const uint32_t it_l = ((i & 1) ? lpos[0] : 0u) ^ ((i & 2) ? lpos[1] : 0u) ^ ((i & 4) ? lpos[2] : 0u) ^ ((i & 8) ? lpos[3] : 0u);
+          const uint32_t it_p = gout ^ ((i & 1) ? pcol[0] : 0u) ^ ((i & 2) ? pcol[1] : 0u) ^ ((i & 4) ? pcol[2] : 0u) ^ ((i & 8) ? pcol[3] : 0u);
+          const double2 x = tile[thr_l ^ it_l];
+          if (DEBUG && (dbg & 8)) continue;
+          if (fin) async_store8(thr_out ^ it_p, x.x * x.x + x.y * x.y, pdst);
+          else async_store16(thr_out ^ it_p, (d2_t){x.x, x.y}, dst);
+        }
       }
     }
-    // ---- the next tile has arrived in registers: all but this wave's 16 tile-out stores are done ----
-    if (DEBUG || first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    first = false;
-#pragma unroll
-    for (int i = 0; i < MAX_TILE_ITERS; ++i) asm volatile("" : "+v"(v[i]));
-    asm volatile("" : "+v"(mp[0]), "+v"(mp[1]));
-    // ---- registers -> LDS: the tile (head CNOTs of the pass folded into the slot) and the matrices ----
-    if (init) {
-      for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
-    } else if (!(dbg & 4)) {
-      const uint32_t slot_t = slot_in ^ xor_map16(g, gbits, in_gmask);
-#pragma unroll
-      for (int i = 0; i < MAX_TILE_ITERS; ++i) {
-        const uint32_t its = ((i & 1) ? imask[0] : 0u) ^ ((i & 2) ? imask[1] : 0u) ^ ((i & 4) ? imask[2] : 0u) ^ ((i & 8) ? imask[3] : 0u);
-        tile[slot_t ^ its] = make_double2(v[i].x, v[i].y);
-      }
-    }
-    if (mat_off[0] >= 0) mats[t] = make_double2(mp[0].x, mp[0].y);
-    if (mat_off[1] >= 0) mats[t + T] = make_double2(mp[1].x, mp[1].y);
-    asm volatile("" ::: "memory");   // the registers are free: LDS writes above, next tile's loads below
-    // ---- the next tile starts its trip from HBM now ----
-    if (Tcur + gridDim.x < total_tiles) BORNVI_PREFETCH(Tcur + gridDim.x);
-    __syncthreads();
-
-    // ---- stages ----
-    const uint32_t* __restrict__ FS = F + FH_WORDS;
-    for (int s = 0; s < nstages; ++s, FS += FS_WORDS) {
-      uint32_t G[10];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) G[i] = FS[i];
-      const uint32_t kind = FS[FS_KIND];
-      const uint32_t my_rw = tab_rw[(uint32_t)s * T + t];
-      const uint32_t my_sg = (kind >> 3) ? tab_sg[(uint32_t)s * T + t] : 0u;
-      const double2* __restrict__ Us = mats + s * 16;
-      // stage kind: number of fused gates (on register bits 0 .. ng-1) | pre sign << 3 | post sign << 4
-#define BORNVI_STAGE(NG, PRE, POST) \
-  case (NG) | ((PRE) << 3) | ((POST) << 4): stage_body<NG, PRE, POST, DEBUG>(tile, Us, my_rw, my_sg, G, dbg); break;
-#define BORNVI_STAGE_NG(PRE, POST) \
-  BORNVI_STAGE(0, PRE, POST) BORNVI_STAGE(1, PRE, POST) BORNVI_STAGE(2, PRE, POST) BORNVI_STAGE(3, PRE, POST) BORNVI_STAGE(4, PRE, POST)
-      switch (kind) {
-        BORNVI_STAGE_NG(0, 0)
-        BORNVI_STAGE_NG(1, 0)
-        BORNVI_STAGE_NG(0, 1)
-        BORNVI_STAGE_NG(1, 1)
-        default: break;
-      }
-#undef BORNVI_STAGE_NG
-#undef BORNVI_STAGE
-      __syncthreads();
-    }
-
-    // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
-    // vector-memory stores per wave (the vmcnt(16) above counts them) ----
+    if (!has_next) break;
+    // ---- stage tables of the NEXT tile's row -> LDS.  The launcher makes the grid a multiple of the tiles per
+    // state whenever it can, so a workgroup keeps its row and this runs once, in trip -1, beside the first prefetch
+    // (these are compiler-tracked loads: they drain vmcnt).  All stages of the current tile are done here. ----
     {
-      const uint32_t gout = xor_cols(g, gbits, P + PW_OUT_GCOL) << out_shift;
-      const uint32_t thr_l = slot_out ^ xor_map16(g, gbits, out_gmask);   // tail CNOTs folded in
-      double2* dst = out + b * state_stride;
-      double* pdst = probs + (b << n);
-#pragma unroll
-      for (int i = 0; i < MAX_TILE_ITERS; ++i) {
-        const uint32_t it_l = ((i & 1) ? lpos[0] : 0u) ^ ((i & 2) ? lpos[1] : 0u) ^ ((i & 4) ? lpos[2] : 0u) ^ ((i & 8) ? lpos[3] : 0u);
-        const uint32_t it_p = gout ^ ((i & 1) ? pcol[0] : 0u) ^ ((i & 2) ? pcol[1] : 0u) ^ ((i & 4) ? pcol[2] : 0u) ^ ((i & 8) ? pcol[3] : 0u);
-        const double2 x = tile[thr_l ^ it_l];
-        if (DEBUG && (dbg & 8)) continue;
-        if (fin) async_store8(thr_out ^ it_p, x.x * x.x + x.y * x.y, pdst);
-        else async_store16(thr_out ^ it_p, (d2_t){x.x, x.y}, dst);
+      const uint32_t gnx = (uint32_t)(Tnext & ((1ll << gbits) - 1));
+      if (gnx != g_tab) {
+        g_tab = gnx;
+        uint32_t tt = t;
+        asm volatile("" : "+v"(tt));
+        const uint32_t row = (gnx << kt) + tt;
+        for (int s = 0; s < nstages; ++s) {
+          tab_rw[(uint32_t)s * T + t] = fast[rw_base + (uint32_t)s * stage_words + row];
+          if ((sign_any >> s) & 1u)
+            tab_sg[(uint32_t)__popc(sign_any & ((1u << s) - 1u)) * T + t] = fast[sg_base + (uint32_t)s * stage_words + row];
+        }
+        if (direct_out) tw_out[tt] = fast[out_tab + row];
       }
     }
-    __syncthreads();   // the tile and the matrices are overwritten by the next tile
+    // ---- the next tile's matrices (the oldest loads in flight: everything but the 16 amplitude loads and the 16
+    // stores behind them is done after vmcnt(32); trip -1 and INIT passes have fewer ops in flight) -> the other buffer ----
+    if (DEBUG || !real) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (init) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    asm volatile("" : "+v"(mp));
+    if (t < npieces) mats_next[t] = make_double2(mp.x, mp.y);
+    __syncthreads();   // the tile is overwritten by the next trip; its matrices are in place
   }
+#undef BORNVI_RUN_STAGE
 #undef BORNVI_PREFETCH
 }
 
@@ -862,7 +952,7 @@ int circuit_fast_workgroups_per_cu(int threads, size_t lds) {
 hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, const uint32_t* fast, uint32_t fast_off,
                                     int n, int k, size_t lds, int batch, const void* in, void* out, double* probs,
                                     const double* gates, long long gate_stride, int max_workgroups, size_t lds_tab_off,
-                                    int dbg, hipStream_t st) {
+                                    size_t lds_mats2_off, int direct_mask, int dbg, hipStream_t st) {
   const long long total_tiles = (long long)batch << (n - k);
   if (total_tiles == 0) return hipSuccess;
   long long wgs = (max_workgroups > 0 && total_tiles > max_workgroups) ? max_workgroups : total_tiles;
@@ -875,11 +965,11 @@ hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, con
   if (!dbg)
     circuit_pass_fast_kernel<false><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
                                                             probs, gates, gate_stride, 1ll << n, total_tiles,
-                                                            (uint32_t)(lds_tab_off / 16), 0);
+                                                            (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, 0);
   else
     circuit_pass_fast_kernel<true><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
                                                            probs, gates, gate_stride, 1ll << n, total_tiles,
-                                                           (uint32_t)(lds_tab_off / 16), dbg);
+                                                           (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, dbg);
   return hipGetLastError();
 }
 

@@ -246,6 +246,49 @@ std::vector<int> order_for_banks(std::vector<int> pos) {
   return out;
 }
 
+// lead / core / trail split of a pass's ops: CNOTs at the head / tail that commute past everything before / after
+// them in the pass are folded into the tile load / store addressing; the rest (core) runs in stages
+void split_pass_ops(const std::vector<Op>& ops, const std::vector<int>& pass_ops, int n, bool is_init,
+                    std::vector<int>& lead, std::vector<int>& core, std::vector<int>& trail) {
+  lead.clear(); core.clear(); trail.clear();
+  std::vector<char> touched(n, 0);
+  std::vector<int> mid;
+  for (int idx : pass_ops) {
+    const Op& o = ops[idx];
+    if (!is_init && o.kind == K_CX && !touched[o.a] && !touched[o.b]) { lead.push_back(idx); continue; }
+    touched[o.a] = 1; if (o.b >= 0) touched[o.b] = 1;
+    mid.push_back(idx);
+  }
+  std::fill(touched.begin(), touched.end(), 0);
+  std::vector<int> trail_rev, core_rev;
+  for (size_t q = mid.size(); q-- > 0;) {
+    const Op& o = ops[mid[q]];
+    if (o.kind == K_CX && !touched[o.a] && !touched[o.b]) { trail_rev.push_back(mid[q]); continue; }
+    touched[o.a] = 1; if (o.b >= 0) touched[o.b] = 1;
+    core_rev.push_back(mid[q]);
+  }
+  core.assign(core_rev.rbegin(), core_rev.rend());
+  trail.assign(trail_rev.rbegin(), trail_rev.rend());
+}
+
+// target wires of the first and of the last stage of a pass (they depend on the ops only, not on the layout)
+void first_last_stage_targets(const std::vector<Op>& ops, const std::vector<int>& pass_ops, int n, int r, bool is_init,
+                              std::vector<int>& first_t, std::vector<int>& last_t) {
+  std::vector<int> lead, core, trail, rest;
+  split_pass_ops(ops, pass_ops, n, is_init, lead, core, trail);
+  first_t.clear(); last_t.clear();
+  std::vector<int> pool = core;
+  bool first = true;
+  while (!pool.empty()) {
+    StageSel sel;
+    stage_select(ops, pool, n, r, sel, rest);
+    if (sel.count() == 0) break;
+    if (first) { first_t = sel.targets; first = false; }
+    last_t = sel.targets;
+    pool = rest;
+  }
+}
+
 struct PassInfo {
   std::vector<int> ops;      // op indices, program order
   std::vector<int> targets;  // wires that must be local
@@ -400,6 +443,20 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     for (int j = 0; j < k; ++j) ldspos[P.lds_wire[j]] = j;
     std::vector<int> pos;
     for (int w : P.local) if (nxt[w]) pos.push_back(ldspos[w]);
+    // Prefer wires that are NOT targets of this pass's last stage nor of the next pass's first stage: those stages
+    // can then move their amplitudes straight between registers and HBM (the low physical bits must come from the
+    // thread index, not from the register wires).  At least 2^4 contiguous elements are kept (256-byte runs).
+    {
+      std::vector<int> f_cur, l_cur, f_nxt, l_nxt;
+      first_last_stage_targets(ops, P.ops, n, r, i == 0 && !spec.in_state, f_cur, l_cur);
+      first_last_stage_targets(ops, passes[i + 1].ops, n, r, false, f_nxt, l_nxt);
+      std::vector<char> busy(n, 0);
+      for (int w : l_cur) busy[w] = 1;
+      for (int w : f_nxt) busy[w] = 1;
+      std::vector<int> quiet;
+      for (int q : pos) if (!busy[P.lds_wire[q]]) quiet.push_back(q);
+      if ((int)quiet.size() >= std::min(4, std::min(opt.lo, k))) pos = quiet;
+    }
     pos = order_for_banks(pos);
     const int lo = std::min((int)pos.size(), std::min(opt.lo, k));
     for (int j = 0; j < lo; ++j) P.out_low.push_back(P.lds_wire[pos[j]]);
@@ -458,26 +515,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     // CNOTs at the head / tail of the pass that commute past everything before / after them in the pass are
     // folded into the tile load / store addressing (GF(2)-linear maps of the tile index): no LDS round trip.
     std::vector<int> lead, core, trail;
-    {
-      std::vector<char> touched(n, 0);
-      std::vector<int> mid;
-      for (int idx : P.ops) {
-        const Op& o = ops[idx];
-        if (!(flags & PASS_INIT) && o.kind == K_CX && !touched[o.a] && !touched[o.b]) { lead.push_back(idx); continue; }
-        touched[o.a] = 1; if (o.b >= 0) touched[o.b] = 1;
-        mid.push_back(idx);
-      }
-      std::fill(touched.begin(), touched.end(), 0);
-      std::vector<int> trail_rev, core_rev;
-      for (size_t q = mid.size(); q-- > 0;) {
-        const Op& o = ops[mid[q]];
-        if (o.kind == K_CX && !touched[o.a] && !touched[o.b]) { trail_rev.push_back(mid[q]); continue; }
-        touched[o.a] = 1; if (o.b >= 0) touched[o.b] = 1;
-        core_rev.push_back(mid[q]);
-      }
-      core.assign(core_rev.rbegin(), core_rev.rend());
-      trail.assign(trail_rev.rbegin(), trail_rev.rend());
-    }
+    split_pass_ops(ops, P.ops, n, (flags & PASS_INIT) != 0, lead, core, trail);
     struct LExpr { uint32_t l, g; };   // slot bit = parity(l & tile index) ^ parity(g & workgroup index)
     auto compose_lin = [&](const std::vector<int>& seq, bool reverse) {
       std::vector<LExpr> ex(k);
@@ -569,14 +607,51 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
         for (int w : sel.targets) if (!has_u[w]) regw.push_back(w);
       }
       for (int w : regw) isr[w] = 1;
-      for (int j = k - 1; j >= 0 && (int)regw.size() < r; --j)
-        if (!isr[P.lds_wire[j]]) { isr[P.lds_wire[j]] = 1; regw.push_back(P.lds_wire[j]); }
+      {   // padding: highest LDS bits first, wires that hold low physical bits of the buffers only as a last resort
+        std::vector<char> lowwire(n, 0);
+        for (int w : P.in_low) lowwire[w] = 1;
+        for (int w : P.out_low) lowwire[w] = 1;
+        for (int avoid = 1; avoid >= 0; --avoid)
+          for (int j = k - 1; j >= 0 && (int)regw.size() < r; --j)
+            if (!isr[P.lds_wire[j]] && !(avoid && lowwire[P.lds_wire[j]])) { isr[P.lds_wire[j]] = 1; regw.push_back(P.lds_wire[j]); }
+      }
       std::vector<int> regbit(n, -1);
       uint32_t rho = 0;
       for (int b = 0; b < r; ++b) { regbit[regw[b]] = b; rho |= (uint32_t)ldspos[regw[b]] << (8 * b); }
       std::vector<int> freepos;
       for (int j = 0; j < k; ++j) if (!isr[P.lds_wire[j]]) freepos.push_back(j);
       freepos = order_for_banks(freepos);
+      // First / last stage of a pass: the fast kernel moves their amplitudes straight between HBM and registers
+      // (no tile fill before the first stage, no tile drain after the last), which coalesces when the low thread
+      // bits sit on the LDS positions of the wires that hold the low physical bits of the buffer read (in_low,
+      // positions 0 .. lo_in-1) resp. written (out_low).  Only the thread-bit ORDER changes; it keeps the
+      // 8-lane ds_write groups and 16-lane ds_read groups conflict-free (positions 0,1,2 | 3 | 4: residues mod 4).
+      uint32_t io_flags = 0;
+      {
+        const bool first = (nstages == 0) && !(flags & PASS_INIT);
+        const bool last = rest.empty();
+        auto lead_with = [&](const std::vector<int>& lowpos) {
+          for (int q : lowpos) if (isr[P.lds_wire[q]]) return false;    // a low wire is a register wire: not possible
+          std::vector<char> taken(k, 0);
+          std::vector<int> others;
+          for (int q : lowpos) taken[q] = 1;
+          for (int q : freepos) if (!taken[q]) others.push_back(q);
+          std::vector<int> ord = lowpos;
+          ord.insert(ord.end(), others.begin(), others.end());
+          freepos = ord;
+          return true;
+        };
+        if (first && !P.in_low.empty()) {
+          std::vector<int> lowpos;
+          for (size_t q = 0; q < P.in_low.size(); ++q) lowpos.push_back((int)q);    // in_low wires sit at LDS bits 0..
+          if ((int)lowpos.size() <= k - r && lead_with(lowpos)) io_flags |= STAGE_FROM_HBM;
+        }
+        if (last && !(io_flags & STAGE_FROM_HBM) && !P.out_low.empty()) {
+          std::vector<int> lowpos;
+          for (int w : P.out_low) lowpos.push_back(ldspos[w]);
+          if ((int)lowpos.size() <= k - r && lead_with(lowpos)) io_flags |= STAGE_TO_HBM;
+        }
+      }
       uint32_t tpos[4] = {0, 0, 0, 0};
       for (size_t j = 0; j < freepos.size() && j < 16; ++j) tpos[j / 4] |= (uint32_t)freepos[j] << (8 * (j % 4));
 
@@ -637,7 +712,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
         W[sbase + 16 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(pre, j)) : 0u;
         W[sbase + 32 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(post, j)) : 0u;
       }
-      uint32_t flags = 0;
+      uint32_t flags = io_flags;
       Expr ident[4];
       for (int t = 0; t < 4; ++t) ident[t] = Expr{1u << t, 0u};
       if (!sel.pre_cz.empty()) { flags |= STAGE_SIGN_PRE; emit_signq(sel.pre_cz, ident); }
@@ -667,7 +742,7 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
 // Evaluates, per (stage, tile, thread), exactly what circuit_pass_kernel computes at run time from the
 // stage header (see also tests/plan_emulator.py, which interprets the same words).
 bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
-  out.words.clear(); out.pass_off.clear(); out.any_sign = false;
+  out.words.clear(); out.pass_off.clear(); out.any_sign = false; out.max_tab_rows = 1;
   const int n = plan.n, k = plan.k;
   if (plan.r != 4 || k < 10 || plan.threads != (1 << (k - 4)) || n - k > 16) return false;
   const int kt = k - 4;
@@ -676,11 +751,11 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
   for (int i = 0; i < plan.n_passes; ++i) {
     const uint32_t* P = plan.words.data() + plan.pass_off[i];
     const uint32_t nst = P[PW_NSTAGES];
-    if (nst > (uint32_t)MAX_STAGES || nst * 16u > 2u * (uint32_t)plan.threads) return false;
+    if (nst > (uint32_t)MAX_STAGES || nst * 16u > (uint32_t)plan.threads) return false;   // one matrix piece per thread
     bool any_sign = false;
     const uint32_t* S = P + PW_STAGES;
-    for (uint32_t s = 0; s < nst; ++s) { if ((S[0] >> 8) & 0xffu) any_sign = true; S += S[0] >> 16; }
-    total += FH_WORDS + (size_t)nst * FS_WORDS + (size_t)nst * per_stage * (any_sign ? 2 : 1);
+    for (uint32_t s = 0; s < nst; ++s) { if ((S[0] >> 8) & (STAGE_SIGN_PRE | STAGE_SIGN_POST)) any_sign = true; S += S[0] >> 16; }
+    total += FH_WORDS + (size_t)nst * FS_WORDS + (size_t)nst * per_stage * (any_sign ? 2 : 1) + 2 * per_stage;
   }
   if (total * sizeof(uint32_t) > max_bytes || total >= (size_t)0xffffffffu) return false;
   std::vector<uint32_t>& W = out.words;
@@ -704,6 +779,7 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
     }
     const bool any_sign = (sign_pre | sign_post) != 0;
     if (any_sign) out.any_sign = true;
+    out.max_tab_rows = std::max(out.max_tab_rows, (int)nst + __builtin_popcount(sign_pre | sign_post));
     const uint32_t rw_base = (uint32_t)W.size();
     W.resize(W.size() + (size_t)nst * per_stage, 0);
     const uint32_t sg_base = any_sign ? (uint32_t)W.size() : 0u;
@@ -758,6 +834,111 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
           if (SG) SG[((size_t)g << kt) + t] = (Qpre ? sign_bits(Qpre, e) : 0u) | ((Qpost ? sign_bits(Qpost, e2) : 0u) << 16);
         }
       S += nwords;
+    }
+    // ---- direct HBM <-> register tables for the first / last stage --------------------------------------------
+    const uint32_t pflags = P[PW_FLAGS];
+    const uint32_t kt2 = (uint32_t)kt;
+    auto tbyte = [&](int table, int j) { return (P[table + (j >> 2)] >> (8 * (j & 3))) & 0xffu; };
+    auto thalf = [&](int table, int j) { return (P[table + (j >> 1)] >> (16 * (j & 1))) & 0xffffu; };
+    const uint32_t ksize = 1u << k;
+    const uint32_t ngl = 1u << (n - k);
+    if (nst > 0) {
+      const uint32_t* S0 = P + PW_STAGES;
+      const uint32_t* SL = S0;
+      for (uint32_t s2 = 0; s2 + 1 < nst; ++s2) SL += SL[0] >> 16;
+      const uint32_t f0 = (S0[0] >> 8) & 0xffu, fl = (SL[0] >> 8) & 0xffu;
+      std::vector<uint32_t> inv(ksize);
+      if ((f0 & STAGE_FROM_HBM) && !(pflags & PASS_INIT)) {
+        // slot(u) = xor_j bit_j(u) IN_MASK[j] ^ xor_m bit_m(g) IN_GMASK[m];  phys(u) = deposit(u, IN_PHYS) | deposit(g, IN_GPHYS)
+        auto slot_lin = [&](uint32_t u) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (u >> j & 1) o ^= thalf(PW_IN_MASK, j); return o; };
+        auto phys_u = [&](uint32_t u) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (u >> j & 1) o |= 1u << tbyte(PW_IN_PHYS, j); return o; };
+        for (uint32_t u = 0; u < ksize; ++u) inv[slot_lin(u)] = u;
+        const uint32_t tab = (uint32_t)W.size();
+        W.resize(W.size() + per_stage, 0);
+        const uint32_t* RW0 = W.data() + rw_base;
+        bool ok = true;
+        uint32_t basis[4];
+        for (int b = 0; b < 4; ++b) basis[b] = phys_u(inv[W[hbase + FH_WORDS + FS_RB + b] >> 4]) << 4;
+        for (uint32_t g = 0; g < ngl && ok; ++g) {
+          uint32_t gslot = 0, gphys = 0;
+          for (int m = 0; m < n - k; ++m) if (g >> m & 1) { gslot ^= thalf(PW_IN_GMASK, m); gphys |= 1u << tbyte(PW_IN_GPHYS, m); }
+          for (uint32_t t = 0; t < (1u << kt2); ++t) {
+            const uint32_t rslot = RW0[((size_t)g << kt2) + t] & 0xffffu;
+            const uint32_t off = (phys_u(inv[rslot ^ gslot]) | gphys) << 4;
+            W[tab + ((size_t)g << kt2) + t] = off;
+          }
+          // every group of 2^lo_in lanes must load one aligned run of 2^lo_in elements (1 KiB at lo_in = 6)
+          const uint32_t lanes = 1u << std::min<uint32_t>(P[PW_LO_IN], 6u);
+          const uint32_t runmask = lanes * 16u - 1u;
+          if (P[PW_LO_IN] < 4u) ok = false;
+          for (uint32_t t0 = 0; t0 < (1u << kt2) && ok; t0 += lanes) {
+            const uint32_t base_run = W[tab + ((size_t)g << kt2) + t0] & ~runmask;
+            uint64_t seen = 0;
+            for (uint32_t l = 0; l < lanes; ++l) {
+              const uint32_t o = W[tab + ((size_t)g << kt2) + t0 + l];
+              if ((o & ~runmask) != base_run) ok = false;
+              seen |= 1ull << ((o >> 4) & (lanes - 1u));
+            }
+            if (seen != (lanes == 64 ? ~0ull : ((1ull << lanes) - 1ull))) ok = false;
+          }
+        }
+        for (int b = 0; b < 4; ++b) if (basis[b] & ((16u << std::min<uint32_t>(P[PW_LO_IN], 6u)) - 1u)) ok = false;   // slot offsets must not move inside the run
+        if (ok) {
+          W[hbase + FH_IN_TAB] = tab;
+          for (int b = 0; b < 4; ++b) W[hbase + FH_IN_BASIS + b] = basis[b];
+        } else {
+          W.resize(tab);
+        }
+      }
+      if (fl & STAGE_TO_HBM) {
+        // out enumeration v: slot(v) = xor_j bit_j(v) OUT_MASK[j] ^ xor_m bit_m(g) OUT_GMASK[m];
+        // phys(v) = xor_j bit_j(v) OUT_COL[j] ^ xor_m bit_m(g) OUT_GCOL[m]
+        const int sh = (pflags & PASS_FINAL) ? 3 : 4;
+        auto slot_lin = [&](uint32_t v) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (v >> j & 1) o ^= thalf(PW_OUT_MASK, j); return o; };
+        auto phys_v = [&](uint32_t v) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (v >> j & 1) o ^= P[PW_OUT_COL + j]; return o; };
+        for (uint32_t v = 0; v < ksize; ++v) inv[slot_lin(v)] = v;
+        const uint32_t tab = (uint32_t)W.size();
+        W.resize(W.size() + per_stage, 0);
+        const uint32_t* RWL = W.data() + rw_base + (size_t)(nst - 1) * per_stage;
+        bool ok = (n + sh) <= 32;
+        uint32_t basis[4];
+        for (int b = 0; b < 4; ++b) basis[b] = phys_v(inv[W[hbase + FH_WORDS + (size_t)(nst - 1) * FS_WORDS + FS_WB + b] >> 4]) << sh;
+        const uint32_t lanes_o = 1u << std::min<uint32_t>(P[PW_LO_OUT], 6u);
+        const uint32_t runmask = (lanes_o << sh) - 1u;
+        if (P[PW_LO_OUT] < 4u && !(pflags & PASS_FINAL)) ok = false;
+        if ((pflags & PASS_FINAL) && P[PW_LO_OUT] < 3u) ok = false;
+        for (uint32_t g = 0; g < ngl && ok; ++g) {
+          uint32_t gslot = 0, gphys = 0;
+          for (int m = 0; m < n - k; ++m) if (g >> m & 1) { gslot ^= thalf(PW_OUT_GMASK, m); gphys ^= P[PW_OUT_GCOL + m]; }
+          for (uint32_t t = 0; t < (1u << kt2); ++t) {
+            const uint32_t wslot = RWL[((size_t)g << kt2) + t] >> 16;
+            W[tab + ((size_t)g << kt2) + t] = (phys_v(inv[wslot ^ gslot]) ^ gphys) << sh;
+          }
+          // every 64-lane store of a slot covers one aligned run of 64 elements -- or two half-filled ones in the
+          // last pass (the wrap-around CNOT of the circuit-ending ring puts the lanes' parity into the top bit)
+          for (uint32_t t0 = 0; t0 < (1u << kt2) && ok; t0 += lanes_o) {
+            uint32_t runs[2] = {0, 0};
+            int nruns = 0;
+            uint64_t seen = 0;
+            for (uint32_t l = 0; l < lanes_o; ++l) {
+              const uint32_t o = W[tab + ((size_t)g << kt2) + t0 + l];
+              const uint32_t rb = o & ~runmask;
+              int f = -1;
+              for (int q = 0; q < nruns; ++q) if (runs[q] == rb) f = q;
+              if (f < 0) { if (nruns == 2) { ok = false; break; } runs[nruns++] = rb; }
+              seen |= 1ull << ((o >> sh) & (lanes_o - 1u));
+            }
+            if (nruns > ((pflags & PASS_FINAL) ? 2 : 1)) ok = false;
+            if (seen != (lanes_o == 64 ? ~0ull : ((1ull << lanes_o) - 1ull))) ok = false;
+          }
+        }
+        if (ok) {
+          W[hbase + FH_OUT_TAB] = tab;
+          for (int b = 0; b < 4; ++b) W[hbase + FH_OUT_BASIS + b] = basis[b];
+        } else {
+          W.resize(tab);
+        }
+      }
     }
   }
   return true;

@@ -100,6 +100,11 @@ constexpr uint32_t PASS_FINAL_STATE = 4u;  // epilogue writes the state itself i
 constexpr int STAGE_HDR_WORDS = 48;
 constexpr uint32_t STAGE_SIGN_PRE = 1u;
 constexpr uint32_t STAGE_SIGN_POST = 2u;
+// thread-bit order of the stage allows the fast kernel to take the stage's amplitudes straight from HBM (first
+// stage of a pass) / to send them straight to HBM (last stage) with coalesced accesses; the generic kernel
+// ignores these flags
+constexpr uint32_t STAGE_FROM_HBM = 4u;
+constexpr uint32_t STAGE_TO_HBM = 8u;
 // sign payload (product of CZ gates = (-1)^{q(x)}, q a quadratic form over the extended index bits):
 //   [0..31] U rows (upper-triangular adjacency), [32..47] m_j (bilinear masks of the 16 slot
 //   offsets), [48] q bits of the slot offsets
@@ -132,10 +137,14 @@ struct Plan {
   // tile + the matrices of the longest pass, rounded up to 512 bytes
   size_t lds_bytes() const { return (size_t(1) << k) * 16 + (((size_t)(max_stages > 0 ? max_stages : 1) * STAGE_MATS_BYTES + 511) / 512) * 512; }
   // fast kernel: the above, then one tile row of the RW (and SG) stage tables of the longest pass
-  size_t fast_lds_tab_off() const { return lds_bytes(); }
-  size_t fast_lds_bytes(bool any_sign) const {
-    return lds_bytes() + (size_t)(max_stages > 0 ? max_stages : 1) * ((size_t)1 << (k - 4)) * 4 * (any_sign ? 2 : 1);
-  }
+  // LDS of the fast kernel: tile | matrices of the current tile | table rows | matrices of the next tile.
+  // `tab_rows` (FastTables::max_tab_rows) = most RW rows + SG rows (sign stages only) any pass needs; four more
+  // rows hold per-thread words (matrix piece, first / last stage HBM offsets).
+  size_t fast_mats_bytes() const { return (size_t)(max_stages > 0 ? max_stages : 1) * STAGE_MATS_BYTES; }
+  size_t fast_lds_tab_off() const { return (size_t(1) << k) * 16 + fast_mats_bytes(); }
+  size_t fast_tab_bytes(int tab_rows) const { return ((size_t)(tab_rows + 4) * ((size_t)1 << (k - 4)) * 4 + 15) / 16 * 16; }
+  size_t fast_lds_mats2_off(int tab_rows) const { return fast_lds_tab_off() + fast_tab_bytes(tab_rows); }
+  size_t fast_lds_bytes(int tab_rows) const { return fast_lds_mats2_off(tab_rows) + fast_mats_bytes(); }
 };
 
 // ---- fast-path tables (kernels_circuit.hip: circuit_pass_fast_kernel) ---------------------------
@@ -153,16 +162,22 @@ struct Plan {
 //       [FS_RB .. +3] byte offset xor-ed into the LDS READ address for register bit i of the slot number
 //       [FS_WB .. +3] same for the WRITE address   (slot offsets are GF(2)-linear in the slot number)
 //   tables: RW[s][g][t] = read slot | write slot << 16;  SG[s][g][t] = pre signs | post signs << 16
-enum FastHeader : int { FH_NSTAGES = 0, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_WORDS = 8 };
+//   direct HBM <-> register stages: [FH_IN_TAB] / [FH_OUT_TAB] word offset of a [g][t] table (0 = none) with the
+//       BYTE offset, inside one state resp. one probability vector, of slot 0 of the thread's group in the buffer the
+//       pass reads (first stage) resp. writes (last stage); slot j is at  offset ^ xor of the FH_IN_BASIS /
+//       FH_OUT_BASIS words of the bits of j  (both address maps are GF(2)-linear)
+enum FastHeader : int { FH_NSTAGES = 0, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_IN_TAB, FH_OUT_TAB,
+                        FH_IN_BASIS = 8, FH_OUT_BASIS = 12, FH_WORDS = 16 };
 enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10, FS_WORDS = 16 };
 
 struct FastTables {
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;   // word offset of each pass's header
   bool any_sign = false;            // some stage carries a CZ sign product (the SG tables exist)
+  int max_tab_rows = 1;             // most (stages + sign stages) of any pass: table rows a workgroup keeps in LDS
 };
-// false (tables empty) when the plan is not eligible: tiles smaller than 2^10, more stage matrices than two
-// per thread, or tables above `max_bytes`; the generic kernel then runs the plan.
+// false (tables empty) when the plan is not eligible: tiles smaller than 2^10, a pass with more 16-byte matrix
+// pieces (16 per stage) than threads, or tables above `max_bytes`; the generic kernel then runs the plan.
 bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out);
 
 // Returns false (with msg) on unsupported sizes.

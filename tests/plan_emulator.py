@@ -21,7 +21,9 @@ STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
 SIGNQ_WORDS = 49
 KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
 # fast-path tables (plan.hpp: FastHeader / FastStage)
-FH_NSTAGES, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_WORDS = 0, 1, 2, 3, 4, 8
+FH_NSTAGES, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_IN_TAB, FH_OUT_TAB = 0, 1, 2, 3, 4, 5, 6
+FH_IN_BASIS, FH_OUT_BASIS, FH_WORDS = 8, 12, 16
+STAGE_FROM_HBM, STAGE_TO_HBM = 4, 8
 FS_FI01, FS_FI23, FS_RB, FS_WB, FS_KIND, FS_WORDS = 0, 1, 2, 6, 10, 16
 
 
@@ -82,8 +84,12 @@ def popc(x):
     return c
 
 
-def fast_stage(F, FH, s, g, k, n, tile, mats):
-    """One stage exactly as circuit_pass_fast_kernel runs it: slots and signs from the planner tables."""
+def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None):
+    """One stage exactly as circuit_pass_fast_kernel runs it: slots and signs from the planner tables.
+    direct_in = (buf, lo_in): the first stage takes its amplitudes straight from the pass's input buffer at the byte
+    offsets of the FH_IN_TAB table (the tile, filled the ordinary way, must hold the same values);
+    direct_out = (phys_of_slot, shift): the last stage's HBM offsets (FH_OUT_TAB) must be where the ordinary tile
+    drain would put each slot."""
     kt = k - 4
     nthr = 1 << kt
     FS = FH + FH_WORDS + s * FS_WORDS
@@ -112,6 +118,22 @@ def fast_stage(F, FH, s, g, k, n, tile, mats):
     assert np.array_equal(np.sort(np.concatenate(wr)), np.arange(1 << k))
     assert np.array_equal(np.sort(np.stack(rd), axis=0), np.sort(np.stack(wr), axis=0))   # a thread's own group
     amp = [tile[rd[j]].copy() for j in range(16)]
+    if direct_in is not None:
+        buf, lo_in = direct_in
+        tab = int(F[FH + FH_IN_TAB])
+        off0 = F[tab + (g << kt): tab + (g << kt) + nthr].astype(np.int64)
+        basis = [int(F[FH + FH_IN_BASIS + b]) for b in range(4)]
+        for j in range(16):
+            off = off0.copy()
+            for b in range(4):
+                if (j >> b) & 1:
+                    off ^= basis[b]
+            assert np.all(off % 16 == 0)
+            np.testing.assert_array_equal(buf[off >> 4], amp[j])      # same amplitudes as through the tile
+            lanes = 1 << min(lo_in, 6)
+            for w0 in range(0, nthr, lanes):                          # each group of 2^lo_in lanes loads one aligned run
+                run = np.sort(off[w0:w0 + lanes])
+                assert np.array_equal(run, (run[0] & ~(16 * lanes - 1)) + 16 * np.arange(lanes))
     if pre or post:
         sgw = F[int(F[FH + FH_SG_BASE]) + s * per_stage + (g << kt): int(F[FH + FH_SG_BASE]) + s * per_stage + (g << kt) + nthr].astype(np.int64)
     if pre:
@@ -130,6 +152,18 @@ def fast_stage(F, FH, s, g, k, n, tile, mats):
             amp[j] = np.where(((sgw >> (16 + j)) & 1).astype(bool), -amp[j], amp[j])
     for j in range(16):
         tile[wr[j]] = amp[j]
+    if direct_out is not None:
+        phys_of_slot, sh = direct_out
+        tab = int(F[FH + FH_OUT_TAB])
+        off0 = F[tab + (g << kt): tab + (g << kt) + nthr].astype(np.int64)
+        basis = [int(F[FH + FH_OUT_BASIS + b]) for b in range(4)]
+        for j in range(16):
+            off = off0.copy()
+            for b in range(4):
+                if (j >> b) & 1:
+                    off ^= basis[b]
+            assert np.all(off % (1 << sh) == 0)
+            np.testing.assert_array_equal(off >> sh, phys_of_slot[wr[j]])    # where the tile drain would write the slot
 
 
 def run_plan(W, mats, state_in=None, fast=None):
@@ -178,8 +212,23 @@ def run_plan(W, mats, state_in=None, fast=None):
                 Fw, Foffs = fast
                 FH = int(Foffs[pi])
                 assert int(Fw[FH + FH_NSTAGES]) == nst
+                # where the ordinary tile drain writes each (logical) tile slot
+                vv = np.arange(ksize, dtype=np.int64)
+                gv = np.full(ksize, g, dtype=np.int64)
+                lds_v = swz_inv(xor_map(vv, k, P, PW_OUT_MASK) ^ xor_map(gv, n - k, P, PW_OUT_GMASK))
+                phys_v = np.zeros(ksize, dtype=np.int64)
+                for j in range(k):
+                    phys_v ^= ((vv >> j) & 1) * int(P[PW_OUT_COL + j])
+                for m in range(n - k):
+                    phys_v ^= ((g >> m) & 1) * int(P[PW_OUT_GCOL + m])
+                phys_of_slot = np.zeros(ksize, dtype=np.int64)
+                phys_of_slot[lds_v] = phys_v
+                use_in = int(Fw[FH + FH_IN_TAB]) != 0 and not (flags & PASS_INIT) and nst > 0
+                use_out = int(Fw[FH + FH_OUT_TAB]) != 0 and nst > 1
                 for si in range(nst):
-                    fast_stage(Fw, FH, si, g, k, n, tile, mats)
+                    fast_stage(Fw, FH, si, g, k, n, tile, mats,
+                               direct_in=(buf, lo_in) if (si == 0 and use_in) else None,
+                               direct_out=(phys_of_slot, 3 if (flags & PASS_FINAL) else 4) if (si == nst - 1 and use_out) else None)
             for si in range(nst if fast is None else 0):
                 # the per-pass matrix table (what the kernel stages into LDS) must agree with the stage header
                 assert int(P[PW_MATS + 2 * si]) == int(S[6]) and int(P[PW_MATS + 2 * si + 1]) == int(S[7])
