@@ -2,12 +2,14 @@
 // kernel sequencing.  No exceptions leave this file; HIP errors are captured into the handle.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "bornvi.h"
 #include "kernels.hpp"
@@ -24,6 +26,18 @@ struct DevPlan {
   FastTables fast;
   uint32_t* d_fast = nullptr;
   int fast_workgroups = 0;   // co-resident workgroups of circuit_pass_fast_kernel on the whole device
+  // prefix sharing of parameter-shift batches (circuit_batch): device tables per (parameter range, chunk capacity)
+  struct ShareChunk {
+    int bc = 0;                        // circuits in the chunk, slot 0 = the base circuit
+    std::vector<int> active, fresh;    // per pass: circuits that run / first circuit that reads the base state
+    int* d_tab = nullptr;              // [bc] shift codes (launch_build_gates), then [bc] output rows
+  };
+  struct ShareTables {
+    int p_begin = 0, p_end = 0, include_base = 0;
+    long long bc_max = 0;
+    std::vector<ShareChunk> chunks;
+  };
+  std::vector<std::unique_ptr<ShareTables>> share_cache;
 };
 
 constexpr size_t FAST_TABLE_MAX_BYTES = (size_t)256 << 20;
@@ -46,6 +60,8 @@ struct bornvi_ctx {
   int wgs_per_cu = 0;   // generic kernel: > 0 = persistent grid of num_cus * wgs_per_cu workgroups; 0 = one per tile
   int fast_path = 1;    // 1: circuit_pass_fast_kernel where the plan is eligible; 0: always the generic kernel
   int fast_wgs_per_cu = 0;  // fast kernel: 0 = what the occupancy query admits
+  int prefix_share = 1;     // parameter-shift batches: a shifted circuit starts from the base circuit's state before the
+                            // first pass its parameter touches (bit-identical results, about half the gate work)
   int direct_stages = 3;    // fast kernel: bit 0 / 1 = first / last stage of a pass straight from / to HBM where the plan allows
                             // (A/B switch; bits 2.. = 1 + the only pass allowed to, for debugging)
 };
@@ -103,6 +119,9 @@ void free_plan(DevPlan* dp) {
   if (dp->d_words) (void)hipFree(dp->d_words);
   if (dp->d_fast) (void)hipFree(dp->d_fast);
   dp->d_words = dp->d_fast = nullptr;
+  for (auto& stb : dp->share_cache)
+    for (auto& c : stb->chunks) if (c.d_tab) (void)hipFree(c.d_tab);
+  dp->share_cache.clear();
 }
 
 // bytes one circuit needs in the workspace: its fused-gate matrices + two ping-pong states
@@ -114,8 +133,11 @@ size_t per_circuit_bytes(const Plan& p) {
 
 // Runs all passes of `dp` for `bc` circuits.  in0: input state of pass 0 (or null for |0..0>);
 // bufA/bufB: ping-pong buffers; final_state / final_probs: destination of the last pass.
+// share (fast path only): see DevPlan::ShareChunk -- pass i runs circuits [0, active[i]), those from fresh[i] on
+// read slot 0 (the base circuit) of the input buffer; the last pass writes row d_tab[bc + b] of final_probs.
 int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA, void* bufB, void* final_state,
-               double* final_probs, const double* gates, long long gate_stride, hipStream_t st) {
+               double* final_probs, const double* gates, long long gate_stride, hipStream_t st,
+               const DevPlan::ShareChunk* share = nullptr, double* trash = nullptr) {
   const Plan& p = dp->plan;
   const void* in = in0;
   for (int i = 0; i < p.n_passes; ++i) {
@@ -123,16 +145,74 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
     if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
       const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * h->num_cus : dp->fast_workgroups;
+      PrefixShare ps;
+      int nb = bc;
+      if (share) {
+        nb = share->active[i];
+        ps.fresh_begin = share->fresh[i];
+        ps.row_map = share->d_tab + share->bc;
+        ps.trash = trash;
+      }
       HIPCHK(h, launch_circuit_pass_fast(dp->d_words, p.pass_off[i], dp->d_fast, dp->fast.pass_off[i], p.n, p.k,
-                                         p.fast_lds_bytes(dp->fast.max_tab_rows), bc, in, out, final_probs, gates, gate_stride, wgs,
+                                         p.fast_lds_bytes(dp->fast.max_tab_rows), nb, in, out, final_probs, gates, gate_stride, wgs,
                                          p.fast_lds_tab_off(), p.fast_lds_mats2_off(dp->fast.max_tab_rows),
                                          ((h->direct_stages >> 2) && (h->direct_stages >> 2) - 1 != i) ? 0 : (h->direct_stages & 3),
-                                         h->debug_flags, st));
+                                         h->debug_flags, ps, st));
     } else {
+      if (share) return fail(h, BORNVI_ERR_INVALID, "prefix sharing needs the fast circuit kernel");
       HIPCHK(h, launch_circuit_pass(dp->d_words, p.pass_off[i], p.n, p.k, p.threads, p.lds_bytes(), bc, in, out, final_probs, gates, gate_stride, h->wgs_per_cu * h->num_cus, h->debug_flags, st));
     }
     in = out;
   }
+  return BORNVI_OK;
+}
+
+// Device tables of a parameter-shift batch with prefix sharing: the 2 (p_end - p_begin) shifted circuits ordered by
+// the first pass their parameter touches (Plan::param_first_pass), cut into chunks of at most bc_max circuits, each
+// led by its own copy of the base circuit.  Built once per (range, capacity) and kept with the plan.
+int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_end, int include_base, long long bc_max,
+                     const DevPlan::ShareTables** out) {
+  for (auto& t : dp->share_cache)
+    if (t->p_begin == p_begin && t->p_end == p_end && t->include_base == include_base && t->bc_max == bc_max) { *out = t.get(); return BORNVI_OK; }
+  const Plan& p = dp->plan;
+  if (dp->share_cache.size() >= 16) {          // (hipFree waits for the device: nothing in flight reads these)
+    for (auto& c : dp->share_cache.front()->chunks) if (c.d_tab) (void)hipFree(c.d_tab);
+    dp->share_cache.erase(dp->share_cache.begin());
+  }
+  std::vector<int> codes;
+  for (int q = p_begin; q < p_end; ++q) { codes.push_back(2 * q); codes.push_back(2 * q + 1); }
+  std::stable_sort(codes.begin(), codes.end(), [&](int a, int b) { return p.param_first_pass[a >> 1] < p.param_first_pass[b >> 1]; });
+  auto tabs = std::make_unique<DevPlan::ShareTables>();
+  tabs->p_begin = p_begin; tabs->p_end = p_end; tabs->include_base = include_base; tabs->bc_max = bc_max;
+  const long long per_chunk = bc_max - 1;
+  for (size_t c0 = 0; c0 < codes.size() || tabs->chunks.empty(); c0 += (size_t)per_chunk) {
+    DevPlan::ShareChunk ch;
+    const size_t c1 = std::min(codes.size(), c0 + (size_t)per_chunk);
+    ch.bc = 1 + (int)(c1 - c0);
+    std::vector<int> host(2 * (size_t)ch.bc);
+    host[0] = -1;
+    host[ch.bc] = (include_base && c0 == 0) ? 0 : -1;
+    for (size_t c = c0; c < c1; ++c) {
+      host[1 + (c - c0)] = codes[c];
+      host[ch.bc + 1 + (c - c0)] = include_base + 2 * ((codes[c] >> 1) - p_begin) + (codes[c] & 1);
+    }
+    ch.active.assign(p.n_passes, 1);
+    ch.fresh.assign(p.n_passes, 1);
+    for (int i = 0; i < p.n_passes; ++i)
+      for (size_t c = c0; c < c1; ++c) {
+        const int fp = p.param_first_pass[codes[c] >> 1];
+        if (fp <= i) ++ch.active[i];
+        if (fp < i) ++ch.fresh[i];
+      }
+    // the last pass must deliver every circuit's probabilities
+    if (ch.active[p.n_passes - 1] != ch.bc) return fail(h, BORNVI_ERR_INVALID, "prefix sharing: a parameter is touched by no pass");
+    HIPCHK(h, hipMalloc((void**)&ch.d_tab, host.size() * sizeof(int)));
+    HIPCHK(h, hipMemcpy(ch.d_tab, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+    tabs->chunks.push_back(std::move(ch));
+    if (codes.empty()) break;
+  }
+  *out = tabs.get();
+  dp->share_cache.push_back(std::move(tabs));
   return BORNVI_OK;
 }
 
@@ -161,9 +241,36 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   void* bufA = base + gates_bytes;
   void* bufB = base + gates_bytes + state_bytes;
   HIPCHK(h, hipSetDevice(h->device));
+  if (shift_mode && h->prefix_share && p.n_passes > 1 && dp->d_fast && h->fast_path && dp->fast_workgroups > 0 &&
+      batch > include_base) {
+    // parameter-shift batch with prefix sharing: [gates | stateA | stateB | trash row]; each chunk carries the
+    // base circuit in slot 0, so one slot of the capacity goes to it
+    const size_t trash_bytes = align_up((size_t)8 << n, 256);
+    if (ws_bytes >= 1024 + trash_bytes + 2 * pcb) {
+      long long cap = (long long)((ws_bytes - 1024 - trash_bytes) / pcb);
+      const long long want = batch - include_base + 1;
+      if (cap > want) cap = want;
+      if (cap > 65535) cap = 65535;
+      const DevPlan::ShareTables* tabs = nullptr;
+      const int p_end = p_begin + (int)((batch - include_base) / 2);
+      rc = get_share_tables(h, dp, p_begin, p_end, include_base, cap, &tabs);
+      if (rc) return rc;
+      const size_t gb = align_up((size_t)cap * p.n_fused * 64, 256);
+      const size_t sb = align_up((size_t)cap * ((size_t)16 << n), 256);
+      void* sA = base + gb;
+      void* sB = base + gb + sb;
+      double* trash = (double*)(base + gb + 2 * sb);
+      for (const DevPlan::ShareChunk& ch : tabs->chunks) {
+        HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, 1, 0, 0, 0, ch.bc, gates, ch.d_tab, st));
+        rc = run_passes(h, dp, ch.bc, nullptr, sA, sB, nullptr, probs, gates, (long long)p.n_fused * 8, st, &ch, trash);
+        if (rc) return rc;
+      }
+      return BORNVI_OK;
+    }
+  }
   for (long long c0 = 0; c0 < batch; c0 += bc_max) {
     const int bc = (int)((batch - c0 < bc_max) ? batch - c0 : bc_max);
-    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, include_base, c0, bc, gates, st));
+    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, include_base, c0, bc, gates, nullptr, st));
     rc = run_passes(h, dp, bc, nullptr, bufA, bufB, nullptr, probs + (c0 << n), gates, (long long)p.n_fused * 8, st);
     if (rc) return rc;
   }
@@ -218,6 +325,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
     return BORNVI_OK;
   }
   if (!std::strcmp(name, "fast_path")) { h->fast_path = value ? 1 : 0; return BORNVI_OK; }
+  if (!std::strcmp(name, "prefix_share")) { h->prefix_share = (int)value; return BORNVI_OK; }
   if (!std::strcmp(name, "direct_stages")) { h->direct_stages = (int)value; return BORNVI_OK; }   // bits 2..: 1 + the only pass allowed (debug)
   if (!std::strcmp(name, "fast_workgroups_per_cu")) {
     if (value < 0 || value > 16) return fail(h, BORNVI_ERR_INVALID, "option value out of range");
@@ -252,8 +360,11 @@ size_t bornvi_circuit_workspace_bytes(bornvi_handle h, int ansatz, int n, int la
   DevPlan* dp = nullptr;
   if (get_plan(h, ansatz, n, layers, &dp)) return 0;
   const Plan& p = dp->plan;
-  size_t b = 512 + align_up((size_t)batch * p.n_fused * 64, 256);
-  if (p.n_passes > 1) b += 2 * align_up((size_t)batch * ((size_t)16 << n), 256);
+  // (one circuit and one probability row more than `batch`: a parameter-shift batch with prefix sharing keeps the
+  // base circuit in slot 0 even when the caller does not ask for its row, and a row for unwanted output)
+  const size_t bb = (size_t)batch + (p.n_passes > 1 ? 1 : 0);
+  size_t b = 1024 + align_up(bb * p.n_fused * 64, 256);
+  if (p.n_passes > 1) b += 2 * align_up(bb * ((size_t)16 << n), 256) + align_up((size_t)8 << n, 256);
   return b;
 }
 

@@ -8,9 +8,18 @@
 namespace bornvi {
 
 // ---- circuit ------------------------------------------------------------------------------------
+// Prefix sharing inside a parameter-shift batch (api.hip: circuit_batch): the circuits of the batch are ordered by
+// the first pass their shifted parameter touches, slot 0 holds the base circuit; a pass runs the circuits that
+// already differ from the base circuit, and those with index >= fresh_begin read the base circuit's state.
+struct PrefixShare {
+  long long fresh_begin = (1ll << 62);   // circuits >= fresh_begin read slot 0 of the input buffer
+  const int* row_map = nullptr;          // final pass: output row of circuit b (< 0: goes to `trash`); null = row b
+  double* trash = nullptr;               // 2^n doubles
+};
+// shift_tab (or null): per circuit of this launch, parameter * 2 + (1 for the minus shift), < 0 for the base circuit
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
                               int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
-                              double* gates, hipStream_t st);
+                              double* gates, const int* shift_tab, hipStream_t st);
 hipError_t prepare_circuit_kernel(size_t lds_bytes);
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,
                                const void* in, void* out, double* probs, const double* gates,
@@ -20,7 +29,7 @@ int circuit_fast_workgroups_per_cu(int threads, size_t lds);
 hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, const uint32_t* fast, uint32_t fast_off,
                                     int n, int k, size_t lds, int batch, const void* in, void* out, double* probs,
                                     const double* gates, long long gate_stride, int max_workgroups, size_t lds_tab_off,
-                                    size_t lds_mats2_off, int direct_mask, int dbg, hipStream_t st);
+                                    size_t lds_mats2_off, int direct_mask, int dbg, const PrefixShare& share, hipStream_t st);
 hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st);
 hipError_t launch_cnot(double* state, int n, long long batch, int control, int target, hipStream_t st);
 hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st);

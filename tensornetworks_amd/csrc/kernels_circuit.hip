@@ -38,7 +38,8 @@ __device__ inline void elem_matrix(uint32_t kind, double t, double (&m)[8]) {
 
 __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const double* __restrict__ thetas,
                                    long long theta_stride, int shift_mode, int p_begin, int include_base,
-                                   long long b_offset, int batch, double* __restrict__ gates) {
+                                   long long b_offset, int batch, double* __restrict__ gates,
+                                   const int* __restrict__ shift_tab) {
   const uint32_t nf = plan[PH_NFUSED];
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)batch * nf) return;
@@ -48,7 +49,10 @@ __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const doub
   const long long bg = b + b_offset;
   uint32_t pshift = 0xfffffffeu;
   double shift = 0.0;
-  if (shift_mode) {
+  if (shift_tab) {                       // circuit b of this launch: parameter * 2 + (1 for the minus shift), < 0: base
+    const int code = shift_tab[b];
+    if (code >= 0) { pshift = (uint32_t)(code >> 1); shift = (code & 1) ? -M_PI_2 : M_PI_2; }
+  } else if (shift_mode) {
     const long long bb = bg - include_base;
     if (bb >= 0) { pshift = (uint32_t)(p_begin + (bb >> 1)); shift = (bb & 1) ? -M_PI_2 : M_PI_2; }
   }
@@ -557,7 +561,8 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const uint32_t* __restrict__ fast, uint32_t fast_off,
     const double2* __restrict__ in, double2* __restrict__ out, double* __restrict__ probs,
     const double* __restrict__ gates, long long gate_stride, long long state_stride, long long total_tiles,
-    uint32_t lds_tab_off /* double2 units */, uint32_t lds_mats2_off /* double2 units */, int direct_mask, int dbg_arg) {
+    uint32_t lds_tab_off /* double2 units */, uint32_t lds_mats2_off /* double2 units */, int direct_mask, int dbg_arg,
+    PrefixShare share) {
   const int dbg = DEBUG ? dbg_arg : 0;
   extern __shared__ double2 tile[];
   const uint32_t* __restrict__ P = plan + pass_off;
@@ -664,7 +669,9 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       /* one per-thread base offset, 16 wave-uniform offsets xor-ed in (both maps are bitwise disjoint or   \
          GF(2)-linear); the empty asm keeps the 16 sums from being hoisted out of the tile loop and spilled */ \
       const uint32_t base_ = tw_in[tt_];                                                             \
-      const double2* src_ = in + bn_ * state_stride + (direct_in ? 0u : deposit16(gn_, 0, gbits, in_gphys)); \
+      /* (a circuit entering the batch in this pass starts from the base circuit's state: slot 0) */ \
+      const double2* src_ = in + (bn_ >= share.fresh_begin ? 0ll : bn_) * state_stride +             \
+                            (direct_in ? 0u : deposit16(gn_, 0, gbits, in_gphys));                  \
       _Pragma("unroll") for (int i = 0; i < MAX_TILE_ITERS; ++i)                                     \
         async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^      \
                                     ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
@@ -701,6 +708,10 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     double2* __restrict__ mats_next = parity ? tile + ksize : mats_b;
     double2* dst = out + b * state_stride;
     double* pdst = probs + (b << n);
+    if (fin && share.row_map) {               // output row of circuit b (rows keep the caller's order; < 0: not wanted)
+      const int row = share.row_map[b];
+      pdst = row < 0 ? share.trash : probs + ((long long)row << n);
+    }
     void* hbm_base = fin ? (void*)pdst : (void*)dst;
     if (real) {
       // ---- the tile has arrived in registers: all but this wave's 16 tile-out stores are done (after trip -1
@@ -920,12 +931,12 @@ hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g3
 // ---- launchers (called from api.hip) --------------------------------------------------------------------
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
                               int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
-                              double* gates, hipStream_t st) {
+                              double* gates, const int* shift_tab, hipStream_t st) {
   const long long total = (long long)batch * nfused;
   if (total == 0) return hipSuccess;
   const int bs = 128;
   build_gates_kernel<<<dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st>>>(
-      plan, thetas, theta_stride, shift_mode, p_begin, include_base, b_offset, batch, gates);
+      plan, thetas, theta_stride, shift_mode, p_begin, include_base, b_offset, batch, gates, shift_tab);
   return hipGetLastError();
 }
 
@@ -952,7 +963,7 @@ int circuit_fast_workgroups_per_cu(int threads, size_t lds) {
 hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, const uint32_t* fast, uint32_t fast_off,
                                     int n, int k, size_t lds, int batch, const void* in, void* out, double* probs,
                                     const double* gates, long long gate_stride, int max_workgroups, size_t lds_tab_off,
-                                    size_t lds_mats2_off, int direct_mask, int dbg, hipStream_t st) {
+                                    size_t lds_mats2_off, int direct_mask, int dbg, const PrefixShare& share, hipStream_t st) {
   const long long total_tiles = (long long)batch << (n - k);
   if (total_tiles == 0) return hipSuccess;
   long long wgs = (max_workgroups > 0 && total_tiles > max_workgroups) ? max_workgroups : total_tiles;
@@ -965,11 +976,11 @@ hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, con
   if (!dbg)
     circuit_pass_fast_kernel<false><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
                                                             probs, gates, gate_stride, 1ll << n, total_tiles,
-                                                            (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, 0);
+                                                            (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, 0, share);
   else
     circuit_pass_fast_kernel<true><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
                                                            probs, gates, gate_stride, 1ll << n, total_tiles,
-                                                           (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, dbg);
+                                                           (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, dbg, share);
   return hipGetLastError();
 }
 

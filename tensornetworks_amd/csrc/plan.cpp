@@ -732,6 +732,23 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     if ((int)nstages > plan.max_stages) plan.max_stages = (int)nstages;
   }
   W[PH_TOTAL] = (uint32_t)W.size();
+  // first pass whose matrices depend on parameter p (a fused gate sits in exactly one stage of one pass)
+  plan.param_first_pass.assign(spec.n_params, np > 0 ? np - 1 : 0);
+  std::vector<char> param_seen(spec.n_params, 0);
+  for (int i = 0; i < np; ++i) {
+    const uint32_t* PWp = W.data() + plan.pass_off[i];
+    for (uint32_t sm = 0; sm < PWp[PW_NSTAGES] * 4u; ++sm) {
+      const uint32_t w = PWp[PW_MATS + (sm >> 1)];
+      const uint32_t f = (sm & 1u) ? (w >> 16) : (w & 0xffffu);
+      if (f == 0xffffu) continue;
+      const uint32_t* fw = W.data() + W[PH_OFF_FUSED] + f * FUSED_WORDS;
+      for (uint32_t e = 0; e < fw[1]; ++e) {
+        const uint32_t par = fw[3 + 2 * e];
+        if (par != 0xffffffffu && par < (uint32_t)spec.n_params && !param_seen[par]) { param_seen[par] = 1; plan.param_first_pass[par] = i; }
+      }
+    }
+  }
+  for (int q = 0; q < spec.n_params; ++q) if (!param_seen[q]) plan.param_first_pass[q] = 0;   // (not in any gate: no saving claimed)
   plan.n = n; plan.k = k; plan.r = r; plan.n_passes = np; plan.n_fused = (int)fused.size();
   plan.n_params = spec.n_params; plan.threads = threads; plan.n_gates = spec.n_gates;
   return true;

@@ -134,6 +134,8 @@ struct Plan {
   int max_stages = 0;   // most stages in any one pass (sizes the LDS matrix area)
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;  // word offset of each pass descriptor
+  std::vector<int> param_first_pass;   // first pass whose matrices depend on parameter p: a circuit that differs from
+                                       // the base circuit only in p has the base circuit's state before that pass
   // tile + the matrices of the longest pass, rounded up to 512 bytes
   size_t lds_bytes() const { return (size_t(1) << k) * 16 + (((size_t)(max_stages > 0 ? max_stages : 1) * STAGE_MATS_BYTES + 511) / 512) * 512; }
   // fast kernel: the above, then one tile row of the RW (and SG) stage tables of the longest pass

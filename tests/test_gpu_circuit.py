@@ -233,3 +233,42 @@ def test_persistent_tile_loop(be, dev, ansatz):
             np.testing.assert_allclose(q[b], ref[pick[b]], rtol=RTOL, atol=ATOL)
     finally:
         be.set_option(dev, "fast_workgroups_per_cu", 0)
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb", [(14, 3, 11), (15, 2, 11), (16, 2, 12)])
+def test_prefix_sharing_is_bit_identical(be, dev, ansatz, n, L, kb, monkeypatch):
+    """A shifted circuit of a parameter-shift batch starts from the base circuit's state before the first pass its
+    parameter touches (prefix_share, default on).  Same passes, same matrices, same order of operations => the rows
+    are BITWISE those of the batch that runs every circuit from |0..0>; and the rows agree with the oracle."""
+    be.set_option(dev, "tile_bits", kb)
+    P = oc.num_params(ansatz, n, L)
+    rng = np.random.default_rng(11 * n + L)
+    th = rng.uniform(-np.pi, np.pi, P)
+    tht = torch.as_tensor(th, device=dev)
+    lo, hi = P // 5, P - P // 7
+    try:
+        be.set_option(dev, "prefix_share", 0)
+        ref_full = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).cpu().numpy()
+        ref_part = be.paramshift_probs(ansatz, n, L, tht, lo, hi, include_base=False).cpu().numpy()
+        be.set_option(dev, "prefix_share", 1)
+        got_full = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).cpu().numpy()
+        got_part = be.paramshift_probs(ansatz, n, L, tht, lo, hi, include_base=False).cpu().numpy()
+        np.testing.assert_array_equal(got_full, ref_full)
+        np.testing.assert_array_equal(got_part, ref_part)
+        # a workspace for ~5 circuits: several chunks, each led by its own copy of the base circuit
+        monkeypatch.setattr(be, "WORKSPACE_CAP", 5 * (2 * 16 * (1 << n)) + 200000)
+        be.release_workspaces()
+        got_chunked = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).cpu().numpy()
+        np.testing.assert_array_equal(got_chunked, ref_full)
+        got_chunked = be.paramshift_probs(ansatz, n, L, tht, lo, hi, include_base=False).cpu().numpy()
+        np.testing.assert_array_equal(got_chunked, ref_part)
+    finally:
+        be.set_option(dev, "prefix_share", 1)
+        be.release_workspaces()
+    # oracle on a few rows: base, first / last parameter, both signs
+    np.testing.assert_allclose(got_full[0], oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)
+    for p_ in (0, P // 2, P - 1):
+        for sgn, row in ((+1, 1 + 2 * p_), (-1, 2 + 2 * p_)):
+            t2 = th.copy(); t2[p_] += sgn * np.pi / 2
+            np.testing.assert_allclose(got_full[row], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
