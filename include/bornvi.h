@@ -88,6 +88,14 @@ int bornvi_paramshift_probs(bornvi_handle h, int ansatz, int n, int layers,
                             const double* theta, int p_begin, int p_end, int include_base,
                             double* probs, void* workspace, size_t workspace_bytes,
                             bornvi_stream stream);
+/* The same for the parameters p_begin, p_begin + p_stride, ... (p_count of them): rows (+p_i, -p_i) in that order.
+ * One rank of W takes p_begin = rank, p_stride = W: with prefix sharing a parameter of an early layer costs more
+ * passes than one of a late layer, and the interleaved deal keeps the ranks level (no reference counterpart: the
+ * reference evaluates all shifts in one process). */
+int bornvi_paramshift_probs_strided(bornvi_handle h, int ansatz, int n, int layers,
+                                    const double* theta, int p_begin, int p_count, int p_stride,
+                                    int include_base, double* probs,
+                                    void* workspace, size_t workspace_bytes, bornvi_stream stream);
 
 /* grad[p - p_begin] = 1/2 * sum_z dLdq[z] (q(theta + pi/2 e_p)[z] - q(theta - pi/2 e_p)[z]).
  * dLdq dev [2^n], grad dev [p_end - p_begin].  Workspace: the circuit workspace for batch

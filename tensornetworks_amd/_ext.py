@@ -46,6 +46,8 @@ _PROTOS = {
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_paramshift_probs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_paramshift_probs_strided": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_paramshift_grad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bornvi_paramshift_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -111,14 +111,16 @@ def circuit_probs(ansatz_type, n, layers, thetas):
     return probs
 
 
-def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=True, out=None, ws_tag="main"):
-    """theta float64 [P] -> probs [(1 if include_base) + 2 (p_end - p_begin), 2^n]:
-    optional base row, then (+p, -p) rows for p in [p_begin, p_end)."""
+def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=True, out=None, ws_tag="main",
+                     p_stride=1):
+    """theta float64 [P] -> probs [(1 if include_base) + 2 count, 2^n]: optional base row, then (+p, -p) rows for
+    p = p_begin, p_begin + p_stride, ... < p_end (count of them; p_stride = 1: the range [p_begin, p_end))."""
     dev = theta.device
     h = _ext.handle_for(dev)
     aid = ansatz_id(ansatz_type)
     _chk(theta, torch.float64, dev, "theta")
-    B = (1 if include_base else 0) + 2 * (p_end - p_begin)
+    count = len(range(p_begin, p_end, p_stride))
+    B = (1 if include_base else 0) + 2 * count
     if out is None:
         out = torch.empty((B, 1 << n), dtype=torch.float64, device=dev)
     else:
@@ -129,23 +131,23 @@ def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base
         return out
     need = _cached_size(h, "bornvi_circuit_workspace_bytes", aid, n, layers, B)
     ws = _ws(dev, min(need, max(WORKSPACE_CAP, _cached_size(h, "bornvi_circuit_workspace_bytes", aid, n, layers, 1))), ws_tag)
-    h.call("bornvi_paramshift_probs", aid, n, layers, _ptr(theta), int(p_begin), int(p_end),
+    h.call("bornvi_paramshift_probs_strided", aid, n, layers, _ptr(theta), int(p_begin), int(count), int(p_stride),
            1 if include_base else 0, _ptr(out), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
     return out
 
 
-def paramshift_grad(ansatz_type, n, layers, theta, dLdq, p_begin, p_end):
-    """grad[p - p_begin] = 1/2 dLdq . (q(theta + pi/2 e_p) - q(theta - pi/2 e_p)), float64."""
+def paramshift_grad(ansatz_type, n, layers, theta, dLdq, p_begin, p_end, p_stride=1):
+    """grad[i] = 1/2 dLdq . (q(theta + pi/2 e_p) - q(theta - pi/2 e_p)) for p = p_begin + i p_stride < p_end, float64."""
     dev = theta.device
     h = _ext.handle_for(dev)
     aid = ansatz_id(ansatz_type)
     _chk(theta, torch.float64, dev, "theta")
     _chk(dLdq, torch.float64, dev, "dLdq")
-    ns = p_end - p_begin
+    ns = len(range(p_begin, p_end, p_stride))
     grad = torch.empty(ns, dtype=torch.float64, device=dev)
     if ns == 0:
         return grad
-    shifted = paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=False)
+    shifted = paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base=False, p_stride=p_stride)
     # dot products on the device: reuse the finishing kernel with ksd2 = 1 (loss = 1, scale = 1/2)
     one = torch.ones(1, dtype=torch.float64, device=dev)
     h.call("bornvi_ksd_grad_finish", n, _ptr(shifted), ns, _ptr(dLdq), _ptr(one), None, None, _ptr(grad),

@@ -33,7 +33,7 @@ struct DevPlan {
     int* d_tab = nullptr;              // [bc] shift codes (launch_build_gates), then [bc] output rows
   };
   struct ShareTables {
-    int p_begin = 0, p_end = 0, include_base = 0;
+    int p_begin = 0, p_count = 0, p_stride = 1, include_base = 0;
     long long bc_max = 0;
     std::vector<ShareChunk> chunks;
   };
@@ -170,20 +170,21 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
 // Device tables of a parameter-shift batch with prefix sharing: the 2 (p_end - p_begin) shifted circuits ordered by
 // the first pass their parameter touches (Plan::param_first_pass), cut into chunks of at most bc_max circuits, each
 // led by its own copy of the base circuit.  Built once per (range, capacity) and kept with the plan.
-int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_end, int include_base, long long bc_max,
+int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_count, int p_stride, int include_base, long long bc_max,
                      const DevPlan::ShareTables** out) {
   for (auto& t : dp->share_cache)
-    if (t->p_begin == p_begin && t->p_end == p_end && t->include_base == include_base && t->bc_max == bc_max) { *out = t.get(); return BORNVI_OK; }
+    if (t->p_begin == p_begin && t->p_count == p_count && t->p_stride == p_stride && t->include_base == include_base &&
+        t->bc_max == bc_max) { *out = t.get(); return BORNVI_OK; }
   const Plan& p = dp->plan;
   if (dp->share_cache.size() >= 16) {          // (hipFree waits for the device: nothing in flight reads these)
     for (auto& c : dp->share_cache.front()->chunks) if (c.d_tab) (void)hipFree(c.d_tab);
     dp->share_cache.erase(dp->share_cache.begin());
   }
   std::vector<int> codes;
-  for (int q = p_begin; q < p_end; ++q) { codes.push_back(2 * q); codes.push_back(2 * q + 1); }
+  for (int i = 0; i < p_count; ++i) { const int q = p_begin + i * p_stride; codes.push_back(2 * q); codes.push_back(2 * q + 1); }
   std::stable_sort(codes.begin(), codes.end(), [&](int a, int b) { return p.param_first_pass[a >> 1] < p.param_first_pass[b >> 1]; });
   auto tabs = std::make_unique<DevPlan::ShareTables>();
-  tabs->p_begin = p_begin; tabs->p_end = p_end; tabs->include_base = include_base; tabs->bc_max = bc_max;
+  tabs->p_begin = p_begin; tabs->p_count = p_count; tabs->p_stride = p_stride; tabs->include_base = include_base; tabs->bc_max = bc_max;
   const long long per_chunk = bc_max - 1;
   for (size_t c0 = 0; c0 < codes.size() || tabs->chunks.empty(); c0 += (size_t)per_chunk) {
     DevPlan::ShareChunk ch;
@@ -194,7 +195,7 @@ int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_end, int i
     host[ch.bc] = (include_base && c0 == 0) ? 0 : -1;
     for (size_t c = c0; c < c1; ++c) {
       host[1 + (c - c0)] = codes[c];
-      host[ch.bc + 1 + (c - c0)] = include_base + 2 * ((codes[c] >> 1) - p_begin) + (codes[c] & 1);
+      host[ch.bc + 1 + (c - c0)] = include_base + 2 * (((codes[c] >> 1) - p_begin) / p_stride) + (codes[c] & 1);
     }
     ch.active.assign(p.n_passes, 1);
     ch.fresh.assign(p.n_passes, 1);
@@ -217,7 +218,7 @@ int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_end, int i
 }
 
 int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batch, const double* thetas,
-                  int shift_mode, int p_begin, int include_base, double* probs, void* ws, size_t ws_bytes,
+                  int shift_mode, int p_begin, int p_stride, int include_base, double* probs, void* ws, size_t ws_bytes,
                   hipStream_t st) {
   if (!h) return BORNVI_ERR_INVALID;
   if (batch < 0 || (!thetas && num_params(ansatz, n, layers) > 0) || (!probs && batch > 0))
@@ -252,8 +253,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
       if (cap > want) cap = want;
       if (cap > 65535) cap = 65535;
       const DevPlan::ShareTables* tabs = nullptr;
-      const int p_end = p_begin + (int)((batch - include_base) / 2);
-      rc = get_share_tables(h, dp, p_begin, p_end, include_base, cap, &tabs);
+      rc = get_share_tables(h, dp, p_begin, (int)((batch - include_base) / 2), p_stride, include_base, cap, &tabs);
       if (rc) return rc;
       const size_t gb = align_up((size_t)cap * p.n_fused * 64, 256);
       const size_t sb = align_up((size_t)cap * ((size_t)16 << n), 256);
@@ -261,7 +261,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
       void* sB = base + gb + sb;
       double* trash = (double*)(base + gb + 2 * sb);
       for (const DevPlan::ShareChunk& ch : tabs->chunks) {
-        HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, 1, 0, 0, 0, ch.bc, gates, ch.d_tab, st));
+        HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, 1, 0, 1, 0, 0, ch.bc, gates, ch.d_tab, st));
         rc = run_passes(h, dp, ch.bc, nullptr, sA, sB, nullptr, probs, gates, (long long)p.n_fused * 8, st, &ch, trash);
         if (rc) return rc;
       }
@@ -270,7 +270,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   }
   for (long long c0 = 0; c0 < batch; c0 += bc_max) {
     const int bc = (int)((batch - c0 < bc_max) ? batch - c0 : bc_max);
-    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, include_base, c0, bc, gates, nullptr, st));
+    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, p_stride, include_base, c0, bc, gates, nullptr, st));
     rc = run_passes(h, dp, bc, nullptr, bufA, bufB, nullptr, probs + (c0 << n), gates, (long long)p.n_fused * 8, st);
     if (rc) return rc;
   }
@@ -370,18 +370,28 @@ size_t bornvi_circuit_workspace_bytes(bornvi_handle h, int ansatz, int n, int la
 
 int bornvi_circuit_probs(bornvi_handle h, int ansatz, int n, int layers, int batch, const double* thetas,
                          double* probs, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
-  return circuit_batch(h, ansatz, n, layers, batch, thetas, 0, 0, 0, probs, workspace, workspace_bytes, (hipStream_t)stream);
+  return circuit_batch(h, ansatz, n, layers, batch, thetas, 0, 0, 1, 0, probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int bornvi_paramshift_probs_strided(bornvi_handle h, int ansatz, int n, int layers, const double* theta, int p_begin,
+                                    int p_count, int p_stride, int include_base, double* probs, void* workspace,
+                                    size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  const int P = num_params(ansatz, n, layers);
+  if (P < 0 || p_begin < 0 || p_count < 0 || p_stride < 1 || (p_count > 0 && (long long)p_begin + (long long)(p_count - 1) * p_stride >= P))
+    return fail(h, BORNVI_ERR_INVALID, "parameter range out of bounds");
+  const long long batch = (include_base ? 1 : 0) + 2ll * p_count;
+  return circuit_batch(h, ansatz, n, layers, batch, theta, 1, p_begin, p_stride, include_base ? 1 : 0, probs, workspace,
+                       workspace_bytes, (hipStream_t)stream);
 }
 
 int bornvi_paramshift_probs(bornvi_handle h, int ansatz, int n, int layers, const double* theta, int p_begin,
                             int p_end, int include_base, double* probs, void* workspace, size_t workspace_bytes,
                             bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
-  const int P = num_params(ansatz, n, layers);
-  if (P < 0 || p_begin < 0 || p_end < p_begin || p_end > P) return fail(h, BORNVI_ERR_INVALID, "parameter range out of bounds");
-  const long long batch = (include_base ? 1 : 0) + 2ll * (p_end - p_begin);
-  return circuit_batch(h, ansatz, n, layers, batch, theta, 1, p_begin, include_base ? 1 : 0, probs, workspace,
-                       workspace_bytes, (hipStream_t)stream);
+  if (p_end < p_begin) return fail(h, BORNVI_ERR_INVALID, "parameter range out of bounds");
+  return bornvi_paramshift_probs_strided(h, ansatz, n, layers, theta, p_begin, p_end - p_begin, 1, include_base, probs,
+                                         workspace, workspace_bytes, stream);
 }
 
 size_t bornvi_paramshift_grad_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers, int p_begin, int p_end) {

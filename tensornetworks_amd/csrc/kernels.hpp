@@ -18,7 +18,7 @@ struct PrefixShare {
 };
 // shift_tab (or null): per circuit of this launch, parameter * 2 + (1 for the minus shift), < 0 for the base circuit
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
-                              int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
+                              int shift_mode, int p_begin, int p_stride, int include_base, long long b_offset, int batch,
                               double* gates, const int* shift_tab, hipStream_t st);
 hipError_t prepare_circuit_kernel(size_t lds_bytes);
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,

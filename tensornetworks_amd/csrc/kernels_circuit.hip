@@ -37,7 +37,7 @@ __device__ inline void elem_matrix(uint32_t kind, double t, double (&m)[8]) {
 }
 
 __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const double* __restrict__ thetas,
-                                   long long theta_stride, int shift_mode, int p_begin, int include_base,
+                                   long long theta_stride, int shift_mode, int p_begin, int p_stride, int include_base,
                                    long long b_offset, int batch, double* __restrict__ gates,
                                    const int* __restrict__ shift_tab) {
   const uint32_t nf = plan[PH_NFUSED];
@@ -54,7 +54,7 @@ __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const doub
     if (code >= 0) { pshift = (uint32_t)(code >> 1); shift = (code & 1) ? -M_PI_2 : M_PI_2; }
   } else if (shift_mode) {
     const long long bb = bg - include_base;
-    if (bb >= 0) { pshift = (uint32_t)(p_begin + (bb >> 1)); shift = (bb & 1) ? -M_PI_2 : M_PI_2; }
+    if (bb >= 0) { pshift = (uint32_t)(p_begin + (bb >> 1) * p_stride); shift = (bb & 1) ? -M_PI_2 : M_PI_2; }
   }
   const double* th = thetas + (shift_mode ? 0 : bg * theta_stride);
   double U[8] = {1, 0, 0, 0, 0, 0, 1, 0};
@@ -930,13 +930,13 @@ hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g3
 
 // ---- launchers (called from api.hip) --------------------------------------------------------------------
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
-                              int shift_mode, int p_begin, int include_base, long long b_offset, int batch,
+                              int shift_mode, int p_begin, int p_stride, int include_base, long long b_offset, int batch,
                               double* gates, const int* shift_tab, hipStream_t st) {
   const long long total = (long long)batch * nfused;
   if (total == 0) return hipSuccess;
   const int bs = 128;
   build_gates_kernel<<<dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st>>>(
-      plan, thetas, theta_stride, shift_mode, p_begin, include_base, b_offset, batch, gates, shift_tab);
+      plan, thetas, theta_stride, shift_mode, p_begin, p_stride, include_base, b_offset, batch, gates, shift_tab);
   return hipGetLastError();
 }
 

@@ -221,13 +221,14 @@ class KSDVariationalInference:
             theta64 = bm.theta.detach().to(device=dev, dtype=torch.float64).contiguous()
         P = theta64.numel()
         rank, ws = shard.world(self.process_group)
-        lo, hi = shard.shard_range(P, rank, ws)
+        lo, hi, step = shard.shard_params(P, rank, ws)
+        n_local = len(range(lo, hi, step))
         overlap = self.overlap_streams
         if overlap is None:
             overlap = False
         if not overlap:
             with self._timed("circuits"):
-                probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True)
+                probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True, p_stride=step)
             q = probs[0]
             shifted = probs[1:]
             with self._timed("stein"):
@@ -251,13 +252,13 @@ class KSDVariationalInference:
                 stein_done = torch.cuda.Event()
                 stein_done.record(aux)
             with self._timed("circuits"):
-                shifted = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=False)
+                shifted = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=False, p_stride=step)
             main.wait_event(stein_done)
             for tns in (ksd2, y, q):
                 tns.record_stream(main)
             theta64.record_stream(aux)
         with self._timed("finish"):
-            loss, grad_local, _ = backend.ksd_grad_finish(n, shifted, hi - lo, y, ksd2)
+            loss, grad_local, _ = backend.ksd_grad_finish(n, shifted, n_local, y, ksd2)
             grad = shard.all_gather_grad(grad_local, P, self.process_group)
         return loss, grad, q
 

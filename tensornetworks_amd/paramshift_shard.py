@@ -1,8 +1,10 @@
 """Sharding of the 2P parameter-shift circuit evaluations across the GPUs of one node.
 
 The shifted circuits of a training step are independent given theta and dL/dq, so rank r of W
-evaluates the parameters [r*ceil(P/W), ...) and the per-parameter gradient scalars (8 bytes
-each) are exchanged with ONE all-gather per step (RCCL over xGMI when the process group uses the
+evaluates the parameters r, r + W, r + 2W, ... (an interleaved deal: with prefix sharing a parameter
+of an early layer costs more passes than one of a late layer, and parameters are numbered layer by
+layer -- contiguous slices would leave rank 0 with all the expensive ones) and the per-parameter
+gradient scalars (8 bytes each) are exchanged with ONE all-gather per step (RCCL over xGMI when the process group uses the
 'nccl' backend; 'gloo' in the CPU tests).  theta, optimiser state, S and K_p are replicated, and
 every rank applies the identical update, so no broadcast is needed.
 
@@ -28,6 +30,12 @@ def shard_range(num_params, rank, world_size):
     lo = min(num_params, rank * chunk)
     hi = min(num_params, lo + chunk)
     return lo, hi
+
+
+def shard_params(num_params, rank, world_size):
+    """(first, stop, stride) of the parameters owned by `rank`: range(first, stop, stride) = rank, rank + W, ...
+    (at most ceil(P/W) of them; the last ranks may own one fewer, or none)."""
+    return min(rank, num_params), num_params, world_size
 
 
 def all_gather_flat(out, msg, group=None):
@@ -58,8 +66,8 @@ def all_reduce_sum(msg, group=None):
 
 
 def all_gather_grad(local_grad, num_params, group=None):
-    """local_grad: this rank's slice (float64, any device the backend supports) -> full [P] vector,
-    identical on every rank."""
+    """local_grad: this rank's gradient scalars for the parameters of shard_params (float64, any device the backend
+    supports) -> full [P] vector in parameter order, identical on every rank."""
     rank, ws = world(group)
     if ws == 1:
         return local_grad
@@ -68,4 +76,5 @@ def all_gather_grad(local_grad, num_params, group=None):
     padded[: local_grad.numel()] = local_grad
     full = torch.empty(chunk * ws, dtype=local_grad.dtype, device=local_grad.device)
     all_gather_flat(full, padded, group)
-    return full[:num_params]
+    # full[r * chunk + i] belongs to parameter i * W + r
+    return full.view(ws, chunk).t().reshape(-1)[:num_params].contiguous()

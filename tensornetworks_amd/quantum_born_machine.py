@@ -64,8 +64,8 @@ class _CircuitProbs(torch.autograd.Function):
         dLdq = grad_out.detach().to(device=dev, dtype=torch.float64).contiguous()
         P = th64.numel()
         rank, ws = shard.world(m.process_group)
-        lo, hi = shard.shard_range(P, rank, ws)
-        local = backend.paramshift_grad(m.ansatz_type, m.num_latent_vars, m.ansatz_layers, th64, dLdq, lo, hi)
+        lo, hi, step = shard.shard_params(P, rank, ws)
+        local = backend.paramshift_grad(m.ansatz_type, m.num_latent_vars, m.ansatz_layers, th64, dLdq, lo, hi, step)
         full = shard.all_gather_grad(local, P, m.process_group)
         return full.to(device=ctx.out_device, dtype=ctx.in_dtype), None
 

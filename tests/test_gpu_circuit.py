@@ -272,3 +272,26 @@ def test_prefix_sharing_is_bit_identical(be, dev, ansatz, n, L, kb, monkeypatch)
         for sgn, row in ((+1, 1 + 2 * p_), (-1, 2 + 2 * p_)):
             t2 = th.copy(); t2[p_] += sgn * np.pi / 2
             np.testing.assert_allclose(got_full[row], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("n,L,kb", [(8, 2, 13), (14, 2, 11)])
+def test_strided_parameter_set(be, dev, n, L, kb):
+    """bornvi_paramshift_probs_strided (the interleaved deal of a multi-GPU step): rows of rank r of W are the rows
+    of parameters r, r + W, ... of the full batch, bit for bit, with and without the base row."""
+    ansatz = "hardware_efficient"
+    be.set_option(dev, "tile_bits", kb)
+    P = oc.num_params(ansatz, n, L)
+    tht = torch.as_tensor(np.random.default_rng(n).uniform(-1, 1, P), device=dev)
+    full = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).cpu().numpy()
+    for W in (2, 3, 8):
+        for r in (0, W - 1):
+            mine = list(range(r, P, W))
+            rows = [0] + [x for p_ in mine for x in (1 + 2 * p_, 2 + 2 * p_)]
+            got = be.paramshift_probs(ansatz, n, L, tht, r, P, include_base=True, p_stride=W).cpu().numpy()
+            np.testing.assert_array_equal(got, full[rows])
+            got = be.paramshift_probs(ansatz, n, L, tht, r, P, include_base=False, p_stride=W).cpu().numpy()
+            np.testing.assert_array_equal(got, full[rows[1:]])
+    w = torch.as_tensor(np.random.default_rng(1).normal(size=2 ** n), device=dev)
+    g_full = be.paramshift_grad(ansatz, n, L, tht, w, 0, P).cpu().numpy()
+    g_str = be.paramshift_grad(ansatz, n, L, tht, w, 1, P, 4).cpu().numpy()
+    np.testing.assert_array_equal(g_str, g_full[1::4])

@@ -181,6 +181,27 @@ def test_shard_ranges_cover_all_parameters():
     assert shard_range(288, 3, 8) == (108, 144) and shard_range(480, 7, 8) == (420, 480)
 
 
+def test_interleaved_parameter_deal_and_gather_order():
+    """shard_params deals the parameters rank, rank + W, ...; all_gather_grad's re-ordering (rank-major gathered
+    buffer -> parameter order) is its exact inverse."""
+    import torch
+    from tensornetworks_amd.paramshift_shard import shard_params
+    for P in (0, 1, 7, 36, 96, 288, 480):
+        for W in (1, 2, 3, 4, 8):
+            chunk = -(-P // W) if P else 0
+            owned = [list(range(*shard_params(P, r, W))) for r in range(W)]
+            assert sorted(sum(owned, [])) == list(range(P))
+            assert all(len(o) <= chunk for o in owned) and max(map(len, owned)) - min(map(len, owned)) <= 1
+            if P == 0:
+                continue
+            gathered = torch.full((W * chunk,), -1.0, dtype=torch.float64)       # what all_gather_into_tensor delivers
+            for r in range(W):
+                gathered[r * chunk: r * chunk + len(owned[r])] = torch.tensor(owned[r], dtype=torch.float64)
+            full = gathered.view(W, chunk).t().reshape(-1)[:P]
+            assert full.tolist() == [float(p) for p in range(P)]
+
+
+
 def test_planner_property_random_configurations():
     """Property test: for random (ansatz, n, layers, tile size) the emitted plan reproduces the oracle."""
     from hypothesis import given, settings, strategies as st

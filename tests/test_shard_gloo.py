@@ -1,4 +1,4 @@
-"""world_size-2 rehearsal (gloo, CPU) of the parameter-shift shard: each rank evaluates its slice of
+"""world_size-2 rehearsal (gloo, CPU) of the parameter-shift shard: each rank evaluates its (interleaved) share of
 the 2P shifted circuits (here with the oracle standing in for the GPU engine), one all-gather of the
 per-parameter gradient scalars, identical optimiser step on every rank."""
 import os
@@ -26,17 +26,17 @@ def _worker(rank, world_size, port, P, ansatz, n, L, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
-        from tensornetworks_amd.paramshift_shard import shard_range, all_gather_grad, world
+        from tensornetworks_amd.paramshift_shard import shard_params, all_gather_grad, world
         assert world() == (rank, world_size)
         rng = np.random.default_rng(0)                      # replicated theta / dLdq
         theta = rng.uniform(-1, 1, P)
         dLdq = rng.normal(size=2 ** n)
-        lo, hi = shard_range(P, rank, world_size)
-        local = np.zeros(hi - lo)
-        for p in range(lo, hi):
+        mine = range(*shard_params(P, rank, world_size))        # rank, rank + W, ...
+        local = np.zeros(len(mine))
+        for i, p in enumerate(mine):
             tp = theta.copy(); tp[p] += np.pi / 2
             tm = theta.copy(); tm[p] -= np.pi / 2
-            local[p - lo] = 0.5 * dLdq @ (oc.probs(ansatz, n, L, tp) - oc.probs(ansatz, n, L, tm))
+            local[i] = 0.5 * dLdq @ (oc.probs(ansatz, n, L, tp) - oc.probs(ansatz, n, L, tm))
         full = all_gather_grad(torch.as_tensor(local), P)
         assert full.shape == (P,)
         th = torch.nn.Parameter(torch.as_tensor(theta, dtype=torch.float32))
