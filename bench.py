@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--fast-wgs-per-cu", type=int, default=-1, help="fast circuit kernel: persistent workgroups per CU (0 = occupancy query)")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (e.g. low_bits=7), repeatable")
     ap.add_argument("--host-sync", type=int, default=0, help="1: loss.item() after every step (reference epoch); 0: read the losses back after the K steps")
+    ap.add_argument("--prefix-share", type=int, default=0,
+                    help="1: headline WITH prefix sharing of the shifted circuits (opt-in extra, SURVEY 8(f) row 4); the default "
+                         "headline runs all 2P+1 circuits in full and reports the shared variant under 'extras'")
+    ap.add_argument("--no-extras", action="store_true", help="skip the labelled extra leg (profiling runs: one variant per trace)")
     ap.add_argument("--overlap", type=int, default=-1, help="1/0: contraction on a second stream beside the shifted circuits")
     args = ap.parse_args()
 
@@ -161,6 +165,7 @@ def main():
         backend.set_option(dev, "fast_path", args.fast_path)
     if args.fast_wgs_per_cu >= 0:
         backend.set_option(dev, "fast_workgroups_per_cu", args.fast_wgs_per_cu)
+    backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
     bn, lat, obs, x = synthetic_network(n, seed=0)
     torch.manual_seed(0)
     vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,
@@ -203,6 +208,35 @@ def main():
     elapsed = time.perf_counter() - t0
     timers = vi.timers
     vi.timers = None
+    # labelled extra: the same K steps with the other setting of prefix sharing (bit-identical shifted distributions,
+    # fewer circuit-passes); not part of `value`
+    extra_share = None
+    if not args.debug_flags and not args.no_extras:
+        backend.set_option(dev, "prefix_share", 0 if args.prefix_share else 1)
+        for _ in range(2):
+            step_fn(params, opt, sched, clip)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        vi.timers = {}
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn(params, opt, sched, clip)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([e2], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e2 = float(tt.item())
+        extra_share = {"prefix_share": 0 if args.prefix_share else 1, "steps_per_sec": round(args.steps / e2, 4),
+                       "ms_per_step": round(1e3 * e2 / args.steps, 4), "circuits_ms": round(mean_ms(vi.timers.get("circuits")), 4),
+                       "note": "same step with prefix sharing of the parameter-shift batch switched "
+                               + ("off" if args.prefix_share else "on") + " (opt-in, bornvi_set_option prefix_share): a shifted "
+                               "circuit starts from the base circuit's state at the first pass its parameter touches; rows bit-identical"}
+        vi.timers = None
+        backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -211,8 +245,7 @@ def main():
     if rank == 0:
         plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)   # same defaults as the handle
         n_passes, n_gates = int(plan[3]), int(plan[11])
-        lo, hi = (0, P) if world == 1 else (0, -(-P // world))
-        circuits_rank = 1 + 2 * (hi - lo)
+        circuits_rank = 1 + 2 * len(range(0, P, world))            # rank 0: the parameters 0, W, 2W, ...
         circ_ms, stein_ms, fin_ms = mean_ms(timers.get("circuits")), mean_ms(timers.get("stein")), mean_ms(timers.get("finish"))
         base_ms = mean_ms(timers.get("base_circuit"))     # > 0 only in overlap mode: base circuit launched separately
         circ_launches = n_passes * (2 if base_ms > 0 else 1)
@@ -225,7 +258,13 @@ def main():
         #   contraction:  the upper triangle of K_p, 4 * 2^n * (2^n + 32) bytes per GPU share (SURVEY 8(d) counts the
         #                 full matrix, 8 * 4^n: `survey_8d_full_matrix_gbs`), or the rank's rows for the row shard
         unfused_bytes = 32.0 * N * n_gates * circuits_rank
-        circ_bytes = circuits_rank * (16.0 * N * (2 * n_passes - 2) + 8.0 * N) if n_passes > 1 else circuits_rank * 8.0 * N
+        # prefix sharing: a shifted circuit joins the batch in the first pass its parameter touches (it reads the base
+        # circuit's state there), so pass i moves only the circuits already active
+        first_pass = _ext.plan_param_first_pass(plan)[list(range(0, P, world))] if n_passes > 1 else None
+        share_on = n_passes > 1 and bool(args.prefix_share)
+        active = [1 + 2 * int((first_pass <= i).sum()) if share_on else circuits_rank for i in range(n_passes)] if n_passes > 1 else [circuits_rank]
+        circ_bytes = sum(a * ((16.0 * N if i > 0 else 0.0) + (16.0 * N if i < n_passes - 1 else 8.0 * N)) for i, a in enumerate(active))
+        circuit_passes_run = sum(active)
         rows_rank = -(-N // world)
         sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
         stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
@@ -255,9 +294,10 @@ def main():
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_kernel_ms, 4),
                                     "avg_launch_ms": round(circ_kernel_ms / circ_launches, 4),
                                     "algorithmic_bytes_per_launch": circ_bytes / circ_launches, "traffic": t_circ,
+                                    "circuit_passes_run": circuit_passes_run, "circuit_passes_without_prefix_sharing": circuits_rank * n_passes,
                                     "survey_8d_unfused_equivalent_gbs": round(unfused_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
-                                    "note": "fused LDS-tiled engine: algorithmic bytes = each state read and written once per "
-                                            "pass; traffic = measured HBM bytes per launch (PMC); the same work as un-fused "
+                                    "note": "fused LDS-tiled engine: algorithmic bytes = each ACTIVE state read and written once per "
+                                            "pass (a shifted circuit starts from the base circuit's state at the first pass its parameter touches); traffic = measured HBM bytes per launch (PMC); the same work as un-fused "
                                             "gate-apply (SURVEY 8(d): 32 * 2^n bytes per gate per state) would need the "
                                             "survey_8d_unfused_equivalent_gbs rate"},
             stein_name: {
@@ -291,7 +331,7 @@ def main():
                        "parallelism": f"paramshift + gram {'strip-pair' if vi._K_pairs is not None else 'row'} shard x{world}",
                        "dist_backend": dist_backend if world > 1 else None,
                        "tile_bits": int(plan[2]), "passes": n_passes},
-            "roofline": roof, "kernels": kern,
+            "roofline": roof, "kernels": kern, "extras": {"prefix_sharing": extra_share},
             "phase_ms": {"circuits": round(circ_ms, 4), "base_circuit": round(base_ms, 4), "stein": round(stein_ms, 4),
                          "finish": round(fin_ms, 4),
                          "note": "event spans; with the contraction on a second stream the 'circuits' and "

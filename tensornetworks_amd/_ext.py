@@ -115,6 +115,30 @@ def plan_words(ansatz_id, n, layers, tile_bits=0):
     return np.frombuffer(buf, dtype=np.uint32).copy()
 
 
+def plan_param_first_pass(words):
+    """First pass whose matrices depend on parameter p, read off a serialised plan (plan.hpp: PW_MATS lists the fused
+    gates of every stage of a pass, a fused gate lists its parameters) -- the same rule the library applies when it
+    orders a parameter-shift batch for prefix sharing (Plan::param_first_pass)."""
+    import numpy as np
+    W = words
+    npass, nparams, off_fused, off_passtab = int(W[3]), int(W[5]), int(W[6]), int(W[7])
+    first = np.full(nparams, -1, dtype=np.int64)
+    for i in range(npass):
+        base = int(W[off_passtab + i])
+        for sm in range(int(W[base + 3]) * 4):                    # PW_NSTAGES stages x 4 register bits
+            w = int(W[base + 128 + (sm >> 1)])                    # PW_MATS
+            f = (w >> 16) if (sm & 1) else (w & 0xffff)
+            if f == 0xffff:
+                continue
+            fw = W[off_fused + f * 10: off_fused + (f + 1) * 10]  # FUSED_WORDS
+            for e in range(int(fw[1])):
+                par = int(fw[3 + 2 * e])
+                if par != 0xffffffff and par < nparams and first[par] < 0:
+                    first[par] = i
+    first[first < 0] = 0
+    return first
+
+
 def plan_fast_words(ansatz_id, n, layers, tile_bits=0):
     """Fast-path tables of a plan: (words, pass offsets), or (None, None) when the plan is not eligible."""
     import numpy as np

@@ -60,8 +60,9 @@ struct bornvi_ctx {
   int wgs_per_cu = 0;   // generic kernel: > 0 = persistent grid of num_cus * wgs_per_cu workgroups; 0 = one per tile
   int fast_path = 1;    // 1: circuit_pass_fast_kernel where the plan is eligible; 0: always the generic kernel
   int fast_wgs_per_cu = 0;  // fast kernel: 0 = what the occupancy query admits
-  int prefix_share = 1;     // parameter-shift batches: a shifted circuit starts from the base circuit's state before the
-                            // first pass its parameter touches (bit-identical results, about half the gate work)
+  int prefix_share = 0;     // OPT-IN: in a parameter-shift batch a shifted circuit starts from the base
+                            // circuit's state before the first pass its parameter touches -- bit-identical rows, ~40 % fewer
+                            // circuit-passes.  Off by default: the north-star path is 2P full circuit evaluations.
   int direct_stages = 3;    // fast kernel: bit 0 / 1 = first / last stage of a pass straight from / to HBM where the plan allows
                             // (A/B switch; bits 2.. = 1 + the only pass allowed to, for debugging)
 };

@@ -239,7 +239,7 @@ def test_persistent_tile_loop(be, dev, ansatz):
 @pytest.mark.parametrize("n,L,kb", [(14, 3, 11), (15, 2, 11), (16, 2, 12)])
 def test_prefix_sharing_is_bit_identical(be, dev, ansatz, n, L, kb, monkeypatch):
     """A shifted circuit of a parameter-shift batch starts from the base circuit's state before the first pass its
-    parameter touches (prefix_share, default on).  Same passes, same matrices, same order of operations => the rows
+    parameter touches (option prefix_share, opt-in).  Same passes, same matrices, same order of operations => the rows
     are BITWISE those of the batch that runs every circuit from |0..0>; and the rows agree with the oracle."""
     be.set_option(dev, "tile_bits", kb)
     P = oc.num_params(ansatz, n, L)
@@ -264,7 +264,7 @@ def test_prefix_sharing_is_bit_identical(be, dev, ansatz, n, L, kb, monkeypatch)
         got_chunked = be.paramshift_probs(ansatz, n, L, tht, lo, hi, include_base=False).cpu().numpy()
         np.testing.assert_array_equal(got_chunked, ref_part)
     finally:
-        be.set_option(dev, "prefix_share", 1)
+        be.set_option(dev, "prefix_share", 0)
         be.release_workspaces()
     # oracle on a few rows: base, first / last parameter, both signs
     np.testing.assert_allclose(got_full[0], oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)

@@ -239,3 +239,21 @@ def test_c_port_matches_numpy_oracle():
     tp = th[0][:20].copy(); tp[3] -= np.pi / 2
     np.testing.assert_allclose(pr[4], oc.probs("basic", 5, 2, tp), atol=1e-15)
     assert pr.shape == (5, 32) and used >= 1
+
+
+def test_param_first_pass_from_plan_words():
+    """Every parameter is touched by some pass, single-pass plans share nothing, and with several passes the early
+    layers' parameters come first (parameters are numbered layer by layer): the ordering prefix sharing relies on."""
+    from tensornetworks_amd import _ext
+    W = _ext.plan_words(_ext.ANSATZ_IDS["hardware_efficient"], 10, 3)
+    assert int(W[3]) == 1 and not _ext.plan_param_first_pass(W).any()
+    for ansatz, n, L in (("hardware_efficient", 16, 6), ("basic", 15, 3), ("all_to_all", 14, 2)):
+        W = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, L)
+        fp = _ext.plan_param_first_pass(W)
+        npass = int(W[3])
+        assert fp.shape == (int(W[5]),) and fp.min() == 0 and fp.max() <= npass - 1
+        assert len(set(fp.tolist())) > 1
+        per_layer = fp.reshape(L, -1) if ansatz != "all_to_all" else None
+        if per_layer is not None:       # the mean first pass grows with the layer
+            m = per_layer.mean(axis=1)
+            assert all(m[i] <= m[i + 1] for i in range(L - 1))

@@ -4,6 +4,6 @@
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /root/repo/gpurun_out/pmc_traffic_$c -- \
-    python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gate-bench ${EXTRA} > /root/repo/gpurun_out/pmc_traffic_$c.log 2>&1
+    python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gate-bench --no-extras ${EXTRA} > /root/repo/gpurun_out/pmc_traffic_$c.log 2>&1
   echo "$c rc=$?"
 done

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 tag=${1:-r01}
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_$tag -- \
-  python3 /root/repo/bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-gate-bench ${EXTRA} > /root/repo/gpurun_out/prof_$tag.log 2>&1
+  python3 /root/repo/bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-gate-bench --no-extras ${EXTRA} > /root/repo/gpurun_out/prof_$tag.log 2>&1
 echo rc=$?
 f=$(ls /root/repo/gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'
