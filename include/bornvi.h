@@ -63,7 +63,10 @@ const char* bornvi_last_error(bornvi_handle h);
  * LDS tile = 2^tile_bits, for every n), "tile_bits_multi" (tile size used only when the state needs
  * several tiles; default 12), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
  * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
- * results are INVALID while non-zero). */
+ * results are INVALID while non-zero).  Engine switches (no effect on results): "fast_path",
+ * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages"; "prefix_share" (default 0; 1: in
+ * bornvi_paramshift_probs* a shifted circuit starts from the base circuit's state at the first pass
+ * its parameter touches instead of |0..0> -- the rows are bit-identical, fewer passes are run). */
 int bornvi_set_option(bornvi_handle h, const char* name, long long value);
 
 /* num_ansatz_params (quantum_born_machine.py:31-38) and gate count of the QNode. */
