@@ -126,7 +126,9 @@ def main():
                     help="1: headline WITH prefix sharing of the shifted circuits (opt-in extra, SURVEY 8(f) row 4); the default "
                          "headline runs all 2P+1 circuits in full and reports the shared variant under 'extras'")
     ap.add_argument("--no-extras", action="store_true", help="skip the labelled extra leg (profiling runs: one variant per trace)")
-    ap.add_argument("--overlap", type=int, default=-1, help="1/0: contraction on a second stream beside the shifted circuits")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="how circuits and contraction share the GPU: 0 in sequence (default), 1 second plain stream, 2 two "
+                         "CU-masked streams (half the CUs each), -1 measured choice between 0 and 2 (choose_overlap)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,7 +173,7 @@ def main():
     vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,
                                  qbm_ansatz_type=ansatz, pytorch_device=str(dev), gram_mode=gram_mode)
     if args.overlap >= 0:
-        vi.overlap_streams = bool(args.overlap)
+        vi.overlap_streams = {0: False, 1: True, 2: "partition"}[args.overlap]
     g = torch.Generator().manual_seed(0)
     P = vi.born_machine.num_ansatz_params
     with torch.no_grad():     # theta0 = 0.1 * randn(P) float32, `small_random` (quantum_born_machine.py:43-45)
@@ -183,6 +185,8 @@ def main():
     vi._prepare_stein(x)
     torch.cuda.synchronize(dev)
     precompute_s = time.perf_counter() - t0
+    if args.overlap < 0:
+        vi.choose_overlap()
 
     total_steps = args.steps + args.warmup
     params, opt, sched = vi.make_optimizer(0.005, total_steps, True, "adam", (0.9, 0.999))
@@ -332,6 +336,8 @@ def main():
                        "dist_backend": dist_backend if world > 1 else None,
                        "tile_bits": int(plan[2]), "passes": n_passes},
             "roofline": roof, "kernels": kern, "extras": {"prefix_sharing": extra_share},
+            "overlap": {"mode": {False: "sequential", True: "second stream", "partition": "cu-partition"}[vi.overlap_streams],
+                        "measured_choice": vi.overlap_choice},
             "phase_ms": {"circuits": round(circ_ms, 4), "base_circuit": round(base_ms, 4), "stein": round(stein_ms, 4),
                          "finish": round(fin_ms, 4),
                          "note": "event spans; with the contraction on a second stream the 'circuits' and "

@@ -59,12 +59,20 @@ void bornvi_destroy(bornvi_handle h);
  * for errors of bornvi_create. */
 const char* bornvi_last_error(bornvi_handle h);
 
+/* A HIP stream restricted to the compute units [first_cu, first_cu + num_cus) of the device
+ * (hipExtStreamCreateWithCUMask): lets the instruction-bound circuit passes and the HBM-bound contraction of one
+ * step run side by side on disjoint halves of the chip instead of taking turns.  Launch the
+ * circuit entry points on such a stream with the option "circuit_cus" = num_cus so that the persistent grid is
+ * sized for it.  No reference counterpart. */
+int bornvi_stream_create_cu_range(bornvi_handle h, int first_cu, int num_cus, bornvi_stream* out);
+int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
+
 /* Tuning knobs of the circuit planner (clears the plan cache): "tile_bits" (4..13, amplitudes per
  * LDS tile = 2^tile_bits, for every n), "tile_bits_multi" (tile size used only when the state needs
  * several tiles; default 12), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
  * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
  * results are INVALID while non-zero).  Engine switches (no effect on results): "fast_path",
- * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages"; "prefix_share" (default 0; 1: in
+ * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus"; "prefix_share" (default 0; 1: in
  * bornvi_paramshift_probs* a shifted circuit starts from the base circuit's state at the first pass
  * its parameter touches instead of |0..0> -- the rows are bit-identical, fewer passes are run). */
 int bornvi_set_option(bornvi_handle h, const char* name, long long value);

@@ -92,6 +92,28 @@ def set_option(dev, name, value):
     h.call("bornvi_set_option", name.encode(), int(value))
 
 
+def set_engine_option(dev, name, value):
+    """Options that do not change plans or workspace sizes (e.g. "circuit_cus"): no cache invalidation."""
+    _ext.handle_for(dev).call("bornvi_set_option", name.encode(), int(value))
+
+
+_cu_streams = {}
+
+
+def cu_range_stream(dev, first_cu, num_cus):
+    """A stream restricted to the CUs [first_cu, first_cu + num_cus) (bornvi_stream_create_cu_range), as a
+    torch.cuda.ExternalStream so that torch events / allocator bookkeeping work with it.  Cached for the process."""
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(first_cu), int(num_cus))
+    if key not in _cu_streams:
+        import ctypes as C
+        h = _ext.handle_for(dev)
+        st = C.c_void_p()
+        h.call("bornvi_stream_create_cu_range", int(first_cu), int(num_cus), C.byref(st))
+        _cu_streams[key] = torch.cuda.ExternalStream(st.value, device=dev)
+    return _cu_streams[key]
+
+
 # ---- circuits -------------------------------------------------------------------------------------
 def circuit_probs(ansatz_type, n, layers, thetas):
     """thetas float64 [B, P] on a cuda device -> probs float64 [B, 2^n]."""

@@ -57,6 +57,7 @@ struct bornvi_ctx {
   size_t max_lds_prepared = 0;
   int debug_flags = 0;  // timing-only ablations of circuit_pass_kernel (results are WRONG when non-zero)
   int num_cus = 256;    // multiProcessorCount
+  int circuit_cus = 0;  // > 0: size the persistent circuit grid for this many CUs (the caller launches on a CU-masked stream)
   int wgs_per_cu = 0;   // generic kernel: > 0 = persistent grid of num_cus * wgs_per_cu workgroups; 0 = one per tile
   int fast_path = 1;    // 1: circuit_pass_fast_kernel where the plan is eligible; 0: always the generic kernel
   int fast_wgs_per_cu = 0;  // fast kernel: 0 = what the occupancy query admits
@@ -145,7 +146,8 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
     const bool last = (i == p.n_passes - 1);
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
     if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
-      const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * h->num_cus : dp->fast_workgroups;
+      const int cus = h->circuit_cus > 0 ? h->circuit_cus : h->num_cus;
+      const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * cus : dp->fast_workgroups / h->num_cus * cus;
       PrefixShare ps;
       int nb = bc;
       if (share) {
@@ -326,6 +328,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
     return BORNVI_OK;
   }
   if (!std::strcmp(name, "fast_path")) { h->fast_path = value ? 1 : 0; return BORNVI_OK; }
+  if (!std::strcmp(name, "circuit_cus")) { h->circuit_cus = (int)value; return BORNVI_OK; }
   if (!std::strcmp(name, "prefix_share")) { h->prefix_share = (int)value; return BORNVI_OK; }
   if (!std::strcmp(name, "direct_stages")) { h->direct_stages = (int)value; return BORNVI_OK; }   // bits 2..: 1 + the only pass allowed (debug)
   if (!std::strcmp(name, "fast_workgroups_per_cu")) {
@@ -367,6 +370,27 @@ size_t bornvi_circuit_workspace_bytes(bornvi_handle h, int ansatz, int n, int la
   size_t b = 1024 + align_up(bb * p.n_fused * 64, 256);
   if (p.n_passes > 1) b += 2 * align_up(bb * ((size_t)16 << n), 256) + align_up((size_t)8 << n, 256);
   return b;
+}
+
+int bornvi_stream_create_cu_range(bornvi_handle h, int first_cu, int num_cus, bornvi_stream* out) {
+  if (!h || !out) return BORNVI_ERR_INVALID;
+  *out = nullptr;
+  if (first_cu < 0 || num_cus < 1 || first_cu + num_cus > h->num_cus) return fail(h, BORNVI_ERR_INVALID, "CU range out of bounds");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<uint32_t> mask((size_t)(h->num_cus + 31) / 32, 0u);
+  for (int c = first_cu; c < first_cu + num_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+  hipStream_t st = nullptr;
+  HIPCHK(h, hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+  *out = (bornvi_stream)st;
+  return BORNVI_OK;
+}
+
+int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!stream) return BORNVI_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamDestroy((hipStream_t)stream));
+  return BORNVI_OK;
 }
 
 int bornvi_circuit_probs(bornvi_handle h, int ansatz, int n, int layers, int batch, const double* thetas,

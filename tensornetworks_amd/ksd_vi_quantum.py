@@ -16,6 +16,7 @@ arithmetic happens:
 S (scores) and K_p are computed once per `train()` call on the GPU.  With a torch.distributed
 process group the 2P shifted circuits are sharded over the ranks (paramshift_shard.py).
 """
+import time
 from functools import partial
 
 import numpy as np
@@ -107,11 +108,18 @@ class KSDVariationalInference:
         self._stein_key = None
         self.timers = None      # optional {name: [(start_event, end_event), ...]} filled by ksd_and_grad
         self.symmetric_contraction = True   # dense mode: contract with the upper triangle of K_p only
-        self.overlap_streams = None         # contraction on a second stream beside the shifted circuits (None =
-                                            # False).  It paid with the one-workgroup-per-tile circuit kernel; the
-                                            # persistent one fills every CU's registers and LDS, so the contraction's
-                                            # waves only get in between passes: measured 5.4-6.3 ms against 5.5 ms
-                                            # in sequence at n = 16
+        # How the shifted circuits and the contraction of a step share the GPU (they need nothing from each other):
+        #   False        in sequence on the current stream
+        #   True         contraction on a second plain stream: paid with the one-workgroup-per-tile circuit kernel; the
+        #                persistent one fills every CU's registers and LDS, so the contraction's waves only get in
+        #                between passes (5.4-6.3 ms against 5.5 ms in sequence at n = 16)
+        #   "partition"  two CU-masked streams: the instruction-bound circuit passes on one half of the CUs, the
+        #                HBM-bound contraction on the other half (bornvi_stream_create_cu_range)
+        #                (measured on the MI355X at n = 16: 5.43 ms against 5.36 ms in sequence -- each kernel alone
+        #                keeps ~80 % of its speed on half the CUs, but together they contend for HBM; no gain)
+        #   None         = False.  `choose_overlap()` decides between False and "partition" by measurement.
+        self.overlap_streams = None
+        self.overlap_choice = None
         self._aux_stream = None
 
     # ---- reference attribute kept lazily (2^n Python tuples) -------------------------------------------
@@ -177,6 +185,37 @@ class KSDVariationalInference:
                 self._K = backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
         self._stein_key = self._key(x_dict)
 
+    def choose_overlap(self, reps=4):
+        """Decides by measurement whether the circuits and the contraction of a step take turns on the whole chip or
+        run side by side on two halves of its CUs ("partition"); call after `_prepare_stein`.  Only where both are
+        sizeable: one GPU, dense Gram, circuits of several passes.  Runs 2 + `reps` gradient evaluations per mode at the current theta (no optimiser
+        step, nothing is kept); both modes produce the same numbers."""
+        rank, ws = shard.world(self.process_group)
+        n = self.num_latent_vars
+        self.overlap_streams = False
+        if ws != 1 or not self._use_dense() or n < 14:
+            return
+        dev = self._S.device
+        theta64 = self.born_machine.theta.detach().to(device=dev, dtype=torch.float64).contiguous()
+        timers, self.timers = self.timers, None
+        took = {}
+        try:
+            for mode in (False, "partition"):
+                self.overlap_streams = mode
+                for _ in range(2):
+                    self.ksd_and_grad(theta64)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    self.ksd_and_grad(theta64)
+                torch.cuda.synchronize(dev)
+                took[mode] = (time.perf_counter() - t0) / reps * 1e3
+        finally:
+            self.timers = timers
+        self.overlap_streams = "partition" if took["partition"] < 0.97 * took[False] else False
+        self.overlap_choice = {"sequential_ms": round(took[False], 4), "partition_ms": round(took["partition"], 4),
+                               "chosen": "partition" if self.overlap_streams else "sequential"}
+
     def _timed(self, name):
         return _EventSpan(self.timers, name)
 
@@ -226,7 +265,40 @@ class KSDVariationalInference:
         overlap = self.overlap_streams
         if overlap is None:
             overlap = False
-        if not overlap:
+        if overlap == "partition":
+            main = torch.cuda.current_stream(dev)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            nc = ncu // 2
+            sc, sa = backend.cu_range_stream(dev, 0, nc), backend.cu_range_stream(dev, nc, ncu - nc)
+            start = torch.cuda.Event()
+            start.record(main)                      # theta64 is produced on the main stream
+            try:
+                with torch.cuda.stream(sa):
+                    sa.wait_event(start)
+                    backend.set_engine_option(dev, "circuit_cus", ncu - nc)
+                    with self._timed("base_circuit"):
+                        q = backend.paramshift_probs(at, n, L, theta64, 0, 0, include_base=True, ws_tag="base")[0]
+                    with self._timed("stein"):
+                        ksd2, y = self._stein_contract(q)
+                    stein_done = torch.cuda.Event()
+                    stein_done.record(sa)
+                with torch.cuda.stream(sc):
+                    sc.wait_event(start)
+                    backend.set_engine_option(dev, "circuit_cus", nc)
+                    with self._timed("circuits"):
+                        shifted = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=False, p_stride=step,
+                                                           ws_tag="part")
+                    circ_done = torch.cuda.Event()
+                    circ_done.record(sc)
+            finally:
+                backend.set_engine_option(dev, "circuit_cus", 0)
+            main.wait_event(stein_done)
+            main.wait_event(circ_done)
+            for tns in (ksd2, y, q, shifted):
+                tns.record_stream(main)
+            theta64.record_stream(sa)
+            theta64.record_stream(sc)
+        elif not overlap:
             with self._timed("circuits"):
                 probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True, p_stride=step)
             q = probs[0]

@@ -218,3 +218,27 @@ def test_async_step_equals_sync_step_and_guards_on_device(dev):
     assert torch.equal(vi.born_machine.theta.detach(), theta_before)
     for k, v in state_before.items():
         assert torch.equal(opt.state[params[0]][k], v), k
+
+
+def test_cu_partition_mode_gives_the_same_step(dev):
+    """overlap_streams = "partition": circuits and contraction on two CU-masked streams (bornvi_stream_create_cu_range)
+    -- same loss, gradient and q as the sequential step, bit for bit (independent computations, only placed differently)."""
+    import torch
+    from tensornetworks_amd.bayesian_network import synthetic_network
+    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+    n, L = 14, 2
+    bn, lat, obs, x = synthetic_network(n, seed=1)
+    torch.manual_seed(0)
+    vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=L, pytorch_device=str(dev),
+                                 gram_mode="dense")
+    vi._prepare_stein(x)
+    vi.overlap_streams = False
+    l0, g0, q0 = vi.ksd_and_grad()
+    vi.overlap_streams = "partition"
+    l1, g1, q1 = vi.ksd_and_grad()
+    l2, g2, q2 = vi.ksd_and_grad()
+    torch.cuda.synchronize()
+    for a, b in ((l0, l1), (g0, g1), (q0, q1), (l0, l2), (g0, g2)):
+        assert torch.equal(a, b)
+    vi.choose_overlap(reps=2)
+    assert vi.overlap_choice["chosen"] in ("sequential", "partition")
