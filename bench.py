@@ -338,6 +338,7 @@ def main():
             "roofline": roof, "kernels": kern, "extras": {"prefix_sharing": extra_share},
             "overlap": {"mode": {False: "sequential", True: "second stream", "partition": "cu-partition"}[vi.overlap_streams],
                         "measured_choice": vi.overlap_choice},
+            "gram_placement": vi.gram_placement,
             "phase_ms": {"circuits": round(circ_ms, 4), "base_circuit": round(base_ms, 4), "stein": round(stein_ms, 4),
                          "finish": round(fin_ms, 4),
                          "note": "event spans; with the contraction on a second stream the 'circuits' and "

@@ -242,3 +242,24 @@ def test_cu_partition_mode_gives_the_same_step(dev):
         assert torch.equal(a, b)
     vi.choose_overlap(reps=2)
     assert vi.overlap_choice["chosen"] in ("sequential", "partition")
+
+
+def test_gram_placement_keeps_an_identical_matrix(dev):
+    """Large dense K_p: _prepare_stein builds several copies in fresh memory, keeps the one the contraction streams
+    fastest (placement matters on this part) and records the timings; the kept matrix is the same bits."""
+    import torch
+    from tensornetworks_amd import backend
+    from tensornetworks_amd.bayesian_network import synthetic_network
+    n = 14                                                       # 2 GiB of K_p
+    bn, lat, obs, x = synthetic_network(n, seed=2)
+    vi = make_vi(bn, lat, obs, n, 1, "hardware_efficient", str(dev), gram_mode="dense")
+    vi._prepare_stein(x)
+    gp = vi.gram_placement
+    assert gp is not None and 1 <= len(gp["contraction_ms_per_try"]) <= vi.gram_placement_tries
+    assert gp["contraction_ms_per_try"][gp["kept"]] == min(gp["contraction_ms_per_try"])
+    ref = backend.stein_gram(vi._S, n, vi.base_kernel_length_scale)
+    assert torch.equal(vi._K, ref)
+    vi.gram_placement_tries = 1
+    vi._stein_key = None
+    vi._prepare_stein(x)
+    assert vi.gram_placement is None and torch.equal(vi._K, ref)
