@@ -295,3 +295,38 @@ def test_strided_parameter_set(be, dev, n, L, kb):
     g_full = be.paramshift_grad(ansatz, n, L, tht, w, 0, P).cpu().numpy()
     g_str = be.paramshift_grad(ansatz, n, L, tht, w, 1, P, 4).cpu().numpy()
     np.testing.assert_array_equal(g_str, g_full[1::4])
+
+
+def test_argument_errors_of_the_shift_entry_points(be, dev):
+    """Out-of-range parameter sets, CU ranges and workspaces are refused with BORNVI_ERR_* (raised as BornviError), not
+    executed: the kernels index with these numbers."""
+    import ctypes as C
+    from tensornetworks_amd import _ext
+    ansatz, n, L = "hardware_efficient", 6, 2
+    P = oc.num_params(ansatz, n, L)
+    tht = torch.zeros(P, dtype=torch.float64, device=dev)
+    h = _ext.handle_for(dev)
+    aid = be.ansatz_id(ansatz)
+    out = torch.empty((2 * P + 1, 1 << n), dtype=torch.float64, device=dev)
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device=dev)
+    args = lambda p0, cnt, stride: ("bornvi_paramshift_probs_strided", aid, n, L, C.c_void_p(tht.data_ptr()), p0, cnt, stride, 1,
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), None)
+    h.call(*args(0, P, 1))                                    # the full set is fine
+    for p0, cnt, stride in ((0, P + 1, 1), (-1, 1, 1), (0, 1, 0), (1, P, 1), (0, P // 2 + 1, 2), (P, 1, 1)):
+        with pytest.raises(_ext.BornviError):
+            h.call(*args(p0, cnt, stride))
+    h.call(*args(P - 1, 1, 7))                                # last parameter alone, any stride
+    with pytest.raises(_ext.BornviError):                     # workspace too small for one circuit is refused at n = 14
+        be.set_option(dev, "tile_bits", 11)
+        t14 = torch.zeros(oc.num_params(ansatz, 14, 1), dtype=torch.float64, device=dev)
+        o14 = torch.empty((3, 1 << 14), dtype=torch.float64, device=dev)
+        h.call("bornvi_paramshift_probs", aid, 14, 1, C.c_void_p(t14.data_ptr()), 0, 1, 1, C.c_void_p(o14.data_ptr()),
+               C.c_void_p(ws.data_ptr()), 4096, None)
+    st = C.c_void_p()
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    for first, cnt in ((-1, 4), (0, 0), (ncu - 1, 2), (0, ncu + 1)):
+        with pytest.raises(_ext.BornviError):
+            h.call("bornvi_stream_create_cu_range", first, cnt, C.byref(st))
+    h.call("bornvi_stream_create_cu_range", 0, ncu // 2, C.byref(st))
+    assert st.value
+    h.call("bornvi_stream_destroy", st)
