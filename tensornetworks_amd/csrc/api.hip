@@ -40,8 +40,6 @@ struct DevPlan {
   std::vector<std::unique_ptr<ShareTables>> share_cache;
 };
 
-constexpr size_t FAST_TABLE_MAX_BYTES = (size_t)256 << 20;
-constexpr size_t MAX_LDS_BYTES = 160 * 1024;   // per CU and per workgroup on gfx950
 
 thread_local std::string g_create_error;
 

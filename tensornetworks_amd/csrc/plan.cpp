@@ -335,6 +335,27 @@ bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& plan
   }
   spec.n_params = num_params(ansatz, n, layers);
   spec.n_gates = (int)gates.size();
+  if (opt.kmulti == 0 && n > opt.kmax && n >= 17 && opt.kmax >= 13) {
+    // Tile size by measurement on the MI355X (tools/tile_sweep_n.py): 2^13 tiles (one 512-thread
+    // workgroup per CU) run a stage ~10 % slower than 2^11 tiles (four 128-thread workgroups per CU), so they pay
+    // when they save at least two of the HBM round trips -- n = 17, 19, 20 yes, n = 18 no -- and only where the fast
+    // kernel can run them (tables and tile within the 160 KiB of LDS).
+    PlanOptions o11 = opt, o13 = opt;
+    o11.kmulti = 11;
+    o13.kmulti = 13;
+    Plan p11, p13;
+    std::string m11, m13;
+    const bool ok11 = build_plan(spec, o11, p11, m11), ok13 = build_plan(spec, o13, p13, m13);
+    bool take13 = ok13 && (!ok11 || p13.n_passes <= p11.n_passes - 2);
+    if (take13 && ok11) {
+      FastTables ft;
+      take13 = build_fast_tables(p13, FAST_TABLE_MAX_BYTES, ft) && p13.fast_lds_bytes(ft.max_tab_rows) <= MAX_LDS_BYTES;
+    }
+    if (take13) { plan = std::move(p13); return true; }
+    if (ok11) { plan = std::move(p11); return true; }
+    msg = m11;
+    return false;
+  }
   return build_plan(spec, opt, plan, msg);
 }
 

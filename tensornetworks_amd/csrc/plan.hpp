@@ -119,11 +119,15 @@ constexpr int SIGNQ_WORDS = 49;
 #endif
 BORNVI_HD inline uint32_t lds_swizzle(uint32_t l) { return l ^ (((l >> 4) ^ (l >> 8) ^ (l >> 12)) & 15u); }
 
+constexpr size_t FAST_TABLE_MAX_BYTES = (size_t)256 << 20;
+constexpr size_t MAX_LDS_BYTES = 160 * 1024;   // per CU and per workgroup on gfx950
+
 struct PlanOptions {
   int kmax = 13;     // largest tile (2^13 complex128 = 128 KiB of LDS): a state of n <= kmax qubits is ONE tile
   int kmulti = 0;    // tile bits when the state needs several tiles (n > kmax).  0 = by measurement on MI355X
                      // (DESIGN.md 4.1): 2^11 (32 KiB, four 128-thread workgroups per CU whose HBM, LDS and FMA
-                     // phases interleave) up to n = 16, 2^12 above (fewer passes over the larger states)
+                     // phases interleave) up to n = 16; above, 2^13 where that saves two or more passes over the
+                     // (then HBM-resident) states, else 2^11 (make_plan)
   int r = 4;         // register wires per stage (2^4 amplitudes per thread)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 512;
