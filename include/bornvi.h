@@ -69,7 +69,7 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
 
 /* Tuning knobs of the circuit planner (clears the plan cache): "tile_bits" (4..13, amplitudes per
  * LDS tile = 2^tile_bits, for every n), "tile_bits_multi" (tile size used only when the state needs
- * several tiles; default 0 = chosen per plan: 11 up to n = 16, above that 13 where it saves two passes), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
+ * several tiles; default 0 = chosen per plan: 11 up to n = 16, above that 13 where it saves an eighth of the passes), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
  * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
  * results are INVALID while non-zero).  Engine switches (no effect on results): "fast_path",
  * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus"; "prefix_share" (default 0; 1: in

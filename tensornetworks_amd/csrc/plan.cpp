@@ -338,15 +338,15 @@ bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& plan
   if (opt.kmulti == 0 && n > opt.kmax && n >= 17 && opt.kmax >= 13) {
     // Tile size by measurement on the MI355X (tools/tile_sweep_n.py): 2^13 tiles (one 512-thread
     // workgroup per CU) run a stage ~10 % slower than 2^11 tiles (four 128-thread workgroups per CU), so they pay
-    // when they save at least two of the HBM round trips -- n = 17, 19, 20 yes, n = 18 no -- and only where the fast
-    // kernel can run them (tables and tile within the 160 KiB of LDS).
+    // when they save at least one in eight of the HBM round trips -- at L = 6: n = 17 (9 -> 7), 19 (10 -> 8), 20 (11 -> 9)
+    // yes, n = 18 (9 -> 8) no -- and only where the fast kernel can run them (tables and tile within 160 KiB of LDS).
     PlanOptions o11 = opt, o13 = opt;
     o11.kmulti = 11;
     o13.kmulti = 13;
     Plan p11, p13;
     std::string m11, m13;
     const bool ok11 = build_plan(spec, o11, p11, m11), ok13 = build_plan(spec, o13, p13, m13);
-    bool take13 = ok13 && (!ok11 || p13.n_passes <= p11.n_passes - 2);
+    bool take13 = ok13 && (!ok11 || p13.n_passes * 8 <= p11.n_passes * 7);
     if (take13 && ok11) {
       FastTables ft;
       take13 = build_fast_tables(p13, FAST_TABLE_MAX_BYTES, ft) && p13.fast_lds_bytes(ft.max_tab_rows) <= MAX_LDS_BYTES;

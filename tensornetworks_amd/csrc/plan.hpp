@@ -126,7 +126,7 @@ struct PlanOptions {
   int kmax = 13;     // largest tile (2^13 complex128 = 128 KiB of LDS): a state of n <= kmax qubits is ONE tile
   int kmulti = 0;    // tile bits when the state needs several tiles (n > kmax).  0 = by measurement on MI355X
                      // (DESIGN.md 4.1): 2^11 (32 KiB, four 128-thread workgroups per CU whose HBM, LDS and FMA
-                     // phases interleave) up to n = 16; above, 2^13 where that saves two or more passes over the
+                     // phases interleave) up to n = 16; above, 2^13 where that saves an eighth or more of the passes over the
                      // (then HBM-resident) states, else 2^11 (make_plan)
   int r = 4;         // register wires per stage (2^4 amplitudes per thread)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)

@@ -330,3 +330,26 @@ def test_argument_errors_of_the_shift_entry_points(be, dev):
     h.call("bornvi_stream_create_cu_range", 0, ncu // 2, C.byref(st))
     assert st.value
     h.call("bornvi_stream_destroy", st)
+
+
+def test_prefix_sharing_with_the_large_tile(be, dev):
+    """n = 17 with the planner's own tile choice (2^13 tiles: one 512-thread workgroup per CU) -- shifted rows with
+    and without prefix sharing are the same bits, and a few of them match the oracle."""
+    ansatz, n, L = "hardware_efficient", 17, 2
+    from tensornetworks_amd import _ext
+    assert int(_ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, L)[2]) == 13
+    P = oc.num_params(ansatz, n, L)
+    th = np.random.default_rng(17).uniform(-np.pi, np.pi, P)
+    tht = torch.as_tensor(th, device=dev)
+    try:
+        be.set_option(dev, "prefix_share", 0)
+        ref = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+        be.set_option(dev, "prefix_share", 1)
+        got = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+        assert torch.equal(ref, got)
+    finally:
+        be.set_option(dev, "prefix_share", 0)
+    got = got.cpu().numpy()
+    np.testing.assert_allclose(got[0], oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)
+    t2 = th.copy(); t2[P - 1] -= np.pi / 2
+    np.testing.assert_allclose(got[2 * P], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
