@@ -226,6 +226,12 @@ int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_
  * float32(grad64) * min(1, max_norm / (||float32(grad64)||_2 + 1e-6)); total_norm dev [1] float32 = that norm. */
 int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double max_norm,
                           float* grad32, float* total_norm, bornvi_stream stream);
+/* The same plus the reference's NaN/Inf guard on the loss (ksd_vi_quantum.py:147-148, "Skipping update") as a device
+ * flag: found_inf dev [1] float32 = 1 if loss (dev [1] float64) is NaN or +-Inf, else 0 -- the form torch's fused
+ * optimisers consume, so a step needs no host read-back of the loss. */
+int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, double max_norm,
+                                const double* loss, float* grad32, float* total_norm,
+                                float* found_inf, bornvi_stream stream);
 
 /* ---- introspection (host only, no GPU needed): serialised execution plan of a circuit ------
  * (passes / stages / fused gates) as uint32 words; used by the CPU tests to check the

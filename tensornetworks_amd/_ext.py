@@ -78,6 +78,8 @@ _PROTOS = {
     "bornvi_ksd_grad_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_clip_cast_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bornvi_clip_cast_grad_guard": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_plan_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t]),
     "bornvi_stream_create_cu_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bornvi_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -86,6 +86,21 @@ def clip_cast_grad(grad64, max_norm):
     return g32, norm
 
 
+def clip_cast_grad_guard(grad64, max_norm, loss):
+    """clip_cast_grad plus the NaN/Inf guard of the loss as a device flag: -> (g32, norm [0-dim], found_inf [0-dim]
+    float32, 1.0 when loss [1] float64 is NaN or +-Inf), one launch."""
+    dev = grad64.device
+    h = _ext.handle_for(dev)
+    _chk(grad64, torch.float64, dev, "grad64")
+    _chk(loss, torch.float64, dev, "loss")
+    g32 = torch.empty(grad64.shape, dtype=torch.float32, device=dev)
+    norm = torch.empty((), dtype=torch.float32, device=dev)
+    found = torch.empty((), dtype=torch.float32, device=dev)
+    h.call("bornvi_clip_cast_grad_guard", grad64.numel(), _ptr(grad64), float(max_norm), _ptr(loss), _ptr(g32), _ptr(norm),
+           _ptr(found), _ext.stream_ptr(dev))
+    return g32, norm, found
+
+
 def set_option(dev, name, value):
     _size_cache.clear()
     h = _ext.handle_for(dev)

@@ -640,7 +640,17 @@ int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double m
   if (!h) return BORNVI_ERR_INVALID;
   if (P < 0 || (P > 0 && (!grad64 || !grad32)) || !total_norm || !(max_norm >= 0.0)) return fail(h, BORNVI_ERR_INVALID, "bad argument");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, (hipStream_t)stream));
+  HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, nullptr, nullptr, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, double max_norm, const double* loss,
+                                float* grad32, float* total_norm, float* found_inf, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (P < 0 || (P > 0 && (!grad64 || !grad32)) || !total_norm || !loss || !found_inf || !(max_norm >= 0.0))
+    return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, loss, found_inf, (hipStream_t)stream));
   return BORNVI_OK;
 }
 

@@ -35,7 +35,8 @@ hipError_t launch_cnot(double* state, int n, long long batch, int control, int t
 hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st);
 hipError_t launch_shift_dot(const double* shifted, int n_shift, const double* w, const double* ksd2, int n,
                             double* grad, double* loss_out, hipStream_t st);
-hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g32, float* norm_out, hipStream_t st);
+hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g32, float* norm_out, const double* loss,
+                            float* found_inf, hipStream_t st);
 hipError_t launch_dldq(const double* y, const double* ksd2, int n, double* dLdq, double* loss_out, hipStream_t st);
 
 // ---- Stein ----------------------------------------------------------------------------------------

@@ -905,8 +905,11 @@ __global__ __launch_bounds__(256) void dldq_kernel(const double* __restrict__ y,
 
 // Gradient hand-off to the optimiser in one launch: float32 cast of the float64 gradient, its 2-norm, and the
 // clip of torch.nn.utils.clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6)); ksd_vi_quantum.py:153).
+// loss / found_inf (both or neither): found_inf = 1.0f when the loss is NaN or +-Inf (the reference skips the update
+// then, ksd_vi_quantum.py:147-148; torch's fused optimisers take this flag on the device), else 0.0f.
 __global__ __launch_bounds__(256) void clip_cast_kernel(const double* __restrict__ g64, int P, double max_norm,
-                                                        float* __restrict__ g32, float* __restrict__ norm_out) {
+                                                        float* __restrict__ g32, float* __restrict__ norm_out,
+                                                        const double* __restrict__ loss, float* __restrict__ found_inf) {
   __shared__ double red[256];
   double acc = 0.0;
   for (int i = threadIdx.x; i < P; i += 256) { const float f = (float)g64[i]; acc += (double)f * (double)f; }
@@ -920,11 +923,15 @@ __global__ __launch_bounds__(256) void clip_cast_kernel(const double* __restrict
   float coef = (float)max_norm / (total + 1e-6f);
   if (coef > 1.0f) coef = 1.0f;
   for (int i = threadIdx.x; i < P; i += 256) g32[i] = (float)g64[i] * coef;
-  if (threadIdx.x == 0) *norm_out = total;
+  if (threadIdx.x == 0) {
+    *norm_out = total;
+    if (found_inf) { const double l = *loss; *found_inf = (l - l == 0.0) ? 0.0f : 1.0f; }   // l - l is NaN for NaN and +-Inf
+  }
 }
 
-hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g32, float* norm_out, hipStream_t st) {
-  clip_cast_kernel<<<1, 256, 0, st>>>(g64, P, max_norm, g32, norm_out);
+hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g32, float* norm_out, const double* loss,
+                            float* found_inf, hipStream_t st) {
+  clip_cast_kernel<<<1, 256, 0, st>>>(g64, P, max_norm, g32, norm_out, loss, found_inf);
   return hipGetLastError();
 }
 

@@ -425,9 +425,9 @@ class KSDVariationalInference:
             raise backend.BornviError("training_step_async needs a float32 theta on the GPU and a fused torch optimiser")
         optimizer_born.zero_grad()
         loss_t, grad64, q = self.ksd_and_grad()
-        g32, grad_norm = backend.clip_cast_grad(grad64, gradient_clip_norm)
+        g32, grad_norm, found_inf = backend.clip_cast_grad_guard(grad64, gradient_clip_norm, loss_t)
         theta.grad = g32
-        optimizer_born.found_inf = torch.logical_not(torch.isfinite(loss_t)).to(torch.float32).reshape(())
+        optimizer_born.found_inf = found_inf
         try:
             optimizer_born.step()
         finally:

@@ -263,3 +263,22 @@ def test_gram_placement_keeps_an_identical_matrix(dev):
     vi._stein_key = None
     vi._prepare_stein(x)
     assert vi.gram_placement is None and torch.equal(vi._K, ref)
+
+
+def test_clip_cast_guard_flags_nonfinite_loss(dev):
+    """bornvi_clip_cast_grad_guard: same gradient and norm as bornvi_clip_cast_grad (and as torch's clip_grad_norm_),
+    found_inf = 1 exactly for NaN / +-Inf losses -- the device-side form of the reference's "Skipping update" guard."""
+    from tensornetworks_amd import backend
+    g = torch.randn(288, dtype=torch.float64, device=dev) * 7.0
+    g32_ref, norm_ref = backend.clip_cast_grad(g, 10.0)
+    t = torch.nn.Parameter(torch.zeros(288, dtype=torch.float32, device=dev))
+    t.grad = g.to(torch.float32)
+    tn = torch.nn.utils.clip_grad_norm_([t], 10.0)
+    for val, want in ((1.25, 0.0), (0.0, 0.0), (-3.0, 0.0), (float("nan"), 1.0), (float("inf"), 1.0), (float("-inf"), 1.0),
+                      (1e308, 0.0), (5e-324, 0.0)):
+        loss = torch.tensor([val], dtype=torch.float64, device=dev)
+        g32, norm, found = backend.clip_cast_grad_guard(g, 10.0, loss)
+        assert torch.equal(g32, g32_ref) and torch.equal(norm, norm_ref)
+        assert float(found) == want, (val, float(found))
+    np.testing.assert_allclose(g32_ref.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(float(norm_ref), float(tn), rtol=1e-6)
