@@ -94,11 +94,11 @@ def cpu_baseline(n, layers, ansatz, S_host, theta64, total_circuits):
     K_rows = cp.gram_rows(S_host, n, 1.0, 0, rows)            # building K is outside the step
     q = np.ascontiguousarray(probs[0])
     cp.gemv_rows(K_rows, n, 0, rows, q)                         # warm
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
+    t_gemv = float("inf")                                       # best of 7: the 0.5 ms sample is at the mercy of one
+    for _ in range(7):                                          # descheduled OpenMP thread (seen: 30 ms once)
+        t0 = time.perf_counter()
         cp.gemv_rows(K_rows, n, 0, rows, q)
-    t_gemv = (time.perf_counter() - t0) / reps
+        t_gemv = min(t_gemv, time.perf_counter() - t0)
     step_s = t_circ * total_circuits / n_circ + t_gemv * (1 << n) / rows
     return {"value": round(1.0 / step_s, 6), "unit": "steps/s", "cores": int(used), "kind": "port",
             "host_cpus": os.cpu_count(),
