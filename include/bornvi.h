@@ -239,6 +239,10 @@ int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, do
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
                                size_t cap_words);
 
+/* Host-only: first pass of the plan whose matrices depend on parameter p (what the opt-in prefix sharing orders a
+ * parameter-shift batch by); returns the number of parameters, or -1 for an unsupported configuration. */
+int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, int* out, int cap);
+
 /* The tables the fast pass kernel reads (one entry per stage, tile and thread: LDS slots with the CNOT
  * index maps folded in, CZ sign bits), derived on the host from the plan above; pass_off_out[i] = word
  * offset of pass i's header.  Returns the number of words, 0 when the plan runs on the generic kernel

@@ -83,6 +83,7 @@ _PROTOS = {
     "bornvi_plan_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t]),
     "bornvi_stream_create_cu_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bornvi_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bornvi_plan_param_first_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "bornvi_plan_fast_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
                                                  C.POINTER(C.c_uint32), C.c_int]),
 }

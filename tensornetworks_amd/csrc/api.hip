@@ -668,6 +668,17 @@ long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uin
   return (long long)p.words.size();
 }
 
+int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, int* out, int cap) {
+  PlanOptions opt;
+  if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
+  Plan p;
+  std::string msg;
+  if (ansatz < 0 || !make_plan(ansatz, n, layers, opt, p, msg)) return -1;
+  if (out)
+    for (int q = 0; q < p.n_params && q < cap; ++q) out[q] = p.param_first_pass[q];
+  return p.n_params;
+}
+
 long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words,
                                     uint32_t* pass_off_out, int cap_passes) {
   PlanOptions opt;

@@ -263,3 +263,20 @@ def test_param_first_pass_from_plan_words():
         if per_layer is not None:       # the mean first pass grows with the layer
             m = per_layer.mean(axis=1)
             assert all(m[i] <= m[i + 1] for i in range(L - 1))
+
+
+def test_first_pass_rule_is_the_librarys():
+    """The parser bench.py uses for its byte accounting (_ext.plan_param_first_pass on the serialised plan) and the
+    planner's own Plan::param_first_pass (what prefix sharing orders the batch by) are the same numbers."""
+    import ctypes as C
+    from tensornetworks_amd import _ext
+    L_ = _ext.lib()
+    for ansatz, n, L in (("hardware_efficient", 16, 6), ("hardware_efficient", 20, 8), ("basic", 15, 3), ("all_to_all", 14, 2),
+                         ("hardware_efficient", 10, 3)):
+        aid = _ext.ANSATZ_IDS[ansatz]
+        P = L_.bornvi_plan_param_first_pass(aid, n, L, 0, None, 0)
+        assert P == len(_ext.plan_param_first_pass(_ext.plan_words(aid, n, L)))
+        buf = (C.c_int * P)()
+        assert L_.bornvi_plan_param_first_pass(aid, n, L, 0, buf, P) == P
+        assert list(buf) == _ext.plan_param_first_pass(_ext.plan_words(aid, n, L)).tolist()
+    assert L_.bornvi_plan_param_first_pass(99, 8, 2, 0, None, 0) == -1
