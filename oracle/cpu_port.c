@@ -167,6 +167,49 @@ double port_gemv_rows(int n, const double* K, long r0, long r1, const double* q,
   return tot;
 }
 
+/* v <- K_base v = M^{(x) n} v, M = [[1, a], [a, 1]]: n butterfly passes (oracle/stein.py kbase_apply) */
+static void kbase_inplace(double* v, int n, double a) {
+  const long N = 1L << n;
+  for (int b = 0; b < n; ++b) {
+    const long st = 1L << b;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < N / 2; ++p) {
+      const long i = ((p & ~(st - 1)) << 1) | (p & (st - 1));
+      const double x0 = v[i], x1 = v[i + st];
+      v[i] = x0 + a * x1;
+      v[i + st] = a * x0 + x1;
+    }
+  }
+}
+
+/* Matrix-free y = K_p q (oracle/stein.py stein_matvec_kron term by term): the CPU side of
+ * bench.py's baseline where the dense Gram does not fit (n = 20).  Returns q . y.  work: 2 * 2^n doubles. */
+double port_kron_matvec(int n, double length_scale, const double* S, const double* q, double* y, double* work) {
+  const long N = 1L << n;
+  const double a = exp(-1.0 / (n * length_scale));
+  double* u = work;
+  double* w = work + N;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < N; ++i) { u[i] = q[i]; y[i] = 0.0; }
+  kbase_inplace(u, n, a);
+  for (int b = 0; b < n; ++b) {
+    const long fm = 1L << (n - 1 - b);               /* tuple position b = bit n-1-b of the index */
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i) w[i] = S[i * n + b] * q[i];
+    kbase_inplace(w, n, a);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i) {
+      const double sb = S[i * n + b];
+      const double du = u[i] - u[i ^ fm], dw = w[i] - w[i ^ fm];
+      y[i] += sb * w[i] - sb * du - dw + 2.0 * du;
+    }
+  }
+  double tot = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : tot)
+  for (long i = 0; i < N; ++i) tot += q[i] * y[i];
+  return tot;
+}
+
 int port_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

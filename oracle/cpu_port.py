@@ -27,6 +27,8 @@ def lib():
         L.port_gram_rows.argtypes = [C.c_int, C.c_double, dp, C.c_long, C.c_long, dp]
         L.port_gemv_rows.restype = C.c_double
         L.port_gemv_rows.argtypes = [C.c_int, dp, C.c_long, C.c_long, dp, dp]
+        L.port_kron_matvec.restype = C.c_double
+        L.port_kron_matvec.argtypes = [C.c_int, C.c_double, dp, dp, dp, dp]
         L.port_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -60,6 +62,16 @@ def gemv_rows(K_rows, n, r0, r1, q):
     y = np.empty(r1 - r0)
     part = lib().port_gemv_rows(n, np.ascontiguousarray(K_rows).reshape(-1), r0, r1, np.ascontiguousarray(q), y)
     return y, part
+
+
+def kron_matvec(S, q, n, length_scale=1.0):
+    """(y = K_p q, q . y) matrix-free."""
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    y = np.empty(1 << n)
+    work = np.empty(2 << n)
+    k2 = lib().port_kron_matvec(n, float(length_scale), S.reshape(-1), q, y, work)
+    return y, k2
 
 
 def max_threads():

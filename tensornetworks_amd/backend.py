@@ -41,7 +41,10 @@ def num_params(ansatz_type, n, layers):
 
 
 def _ws(dev, nbytes, tag="main"):
-    key = (dev.index, tag)
+    """Cached workspace, one per (device, purpose, STREAM): a buffer is only ever used on the stream it was allocated
+    on, so the caching allocator's stream-ordered reuse stays valid when a workspace is re-grown (the overlap modes
+    launch on auxiliary / CU-masked streams)."""
+    key = (dev.index, tag, int(torch.cuda.current_stream(dev).cuda_stream))
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         _workspaces[key] = None
@@ -54,9 +57,17 @@ def release_workspaces():
     _workspaces.clear()
 
 
-def _chk(t, dtype, dev, name):
+def _chk(t, dtype, dev, name, numel=None):
+    """dtype / device / contiguity and (the C ABI sees raw pointers only) the element count the kernels will index."""
     if t.dtype != dtype or t.device != dev or not t.is_contiguous():
         raise BornviError(f"{name}: expected contiguous {dtype} on {dev}, got {t.dtype} on {t.device}")
+    if numel is not None and t.numel() != int(numel):
+        raise BornviError(f"{name}: expected {int(numel)} elements, got {t.numel()} (shape {tuple(t.shape)})")
+
+
+def _chk_n(n, lo=1, hi=30):
+    if not (isinstance(n, (int, np.integer)) and lo <= int(n) <= hi):
+        raise BornviError(f"number of qubits / latent variables out of range: {n!r}")
 
 
 def _ptr(t):
@@ -135,6 +146,7 @@ def circuit_probs(ansatz_type, n, layers, thetas):
     dev = thetas.device
     h = _ext.handle_for(dev)
     aid = ansatz_id(ansatz_type)
+    _chk_n(n)
     P = num_params(ansatz_type, n, layers)
     if thetas.dim() != 2 or thetas.shape[1] != P:
         raise BornviError(f"thetas must be [batch, {P}]")
@@ -155,7 +167,8 @@ def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base
     dev = theta.device
     h = _ext.handle_for(dev)
     aid = ansatz_id(ansatz_type)
-    _chk(theta, torch.float64, dev, "theta")
+    _chk_n(n)
+    _chk(theta, torch.float64, dev, "theta", num_params(ansatz_type, n, layers))
     count = len(range(p_begin, p_end, p_stride))
     B = (1 if include_base else 0) + 2 * count
     if out is None:
@@ -178,8 +191,9 @@ def paramshift_grad(ansatz_type, n, layers, theta, dLdq, p_begin, p_end, p_strid
     dev = theta.device
     h = _ext.handle_for(dev)
     aid = ansatz_id(ansatz_type)
-    _chk(theta, torch.float64, dev, "theta")
-    _chk(dLdq, torch.float64, dev, "dLdq")
+    _chk_n(n)
+    _chk(theta, torch.float64, dev, "theta", num_params(ansatz_type, n, layers))
+    _chk(dLdq, torch.float64, dev, "dLdq", 1 << n)
     ns = len(range(p_begin, p_end, p_stride))
     grad = torch.empty(ns, dtype=torch.float64, device=dev)
     if ns == 0:
@@ -196,7 +210,10 @@ def gate1q_apply(state, n, wire, U):
     """In-place one-qubit gate on state complex128 [B, 2^n] (one HBM round trip)."""
     dev = state.device
     h = _ext.handle_for(dev)
+    _chk_n(n, 1, 40)
     _chk(state, torch.complex128, dev, "state")
+    if state.numel() % (1 << n):
+        raise BornviError("state: element count is not a multiple of 2^n")
     Uh = np.ascontiguousarray(np.asarray(U, dtype=np.complex128).reshape(4)).view(np.float64)
     arr = (C.c_double * 8)(*Uh.tolist())
     h.call("bornvi_gate1q_apply", n, state.numel() >> n, _ptr(state), int(wire), arr, _ext.stream_ptr(dev))
@@ -206,7 +223,10 @@ def gate1q_apply(state, n, wire, U):
 def cnot_apply(state, n, control, target):
     dev = state.device
     h = _ext.handle_for(dev)
+    _chk_n(n, 2, 40)
     _chk(state, torch.complex128, dev, "state")
+    if state.numel() % (1 << n):
+        raise BornviError("state: element count is not a multiple of 2^n")
     h.call("bornvi_cnot_apply", n, state.numel() >> n, _ptr(state), int(control), int(target), _ext.stream_ptr(dev))
     return state
 
@@ -214,7 +234,10 @@ def cnot_apply(state, n, control, target):
 def born_probs(state, n):
     dev = state.device
     h = _ext.handle_for(dev)
+    _chk_n(n, 0, 40)
     _chk(state, torch.complex128, dev, "state")
+    if state.numel() % (1 << n):
+        raise BornviError("state: element count is not a multiple of 2^n")
     probs = torch.empty(state.shape, dtype=torch.float64, device=dev)
     h.call("bornvi_born_probs", n, state.numel() >> n, _ptr(state), _ptr(probs), _ext.stream_ptr(dev))
     return probs
@@ -240,8 +263,11 @@ def stein_gram(S, n, length_scale=1.0, rows=None, out=None):
     a contiguous [rows, 2^n] float64 destination (e.g. a slice of a larger buffer)."""
     dev = S.device
     h = _ext.handle_for(dev)
-    _chk(S, torch.float64, dev, "S")
+    _chk_n(n, 1, 17)
+    _chk(S, torch.float64, dev, "S", n << n)
     r0, r1 = (0, 1 << n) if rows is None else (int(rows[0]), int(rows[1]))
+    if not (0 <= r0 <= r1 <= (1 << n)):
+        raise BornviError("stein_gram: row range out of bounds")
     K = torch.empty((r1 - r0, 1 << n), dtype=torch.float64, device=dev) if out is None else out
     if out is not None:
         _chk(out, torch.float64, dev, "out")
@@ -272,13 +298,17 @@ def stein_quadform_sym_pairs(K_lo, K_hi, pa, pb, q, n, out=None):
     returns a [2^n + 1] vector (y_partial followed by ksd2_partial) -- the message of the all-reduce."""
     dev = q.device
     h = _ext.handle_for(dev)
-    _chk(q, torch.float64, dev, "q")
-    if pb > pa:
-        _chk(K_lo, torch.float64, dev, "K_lo")
-        _chk(K_hi, torch.float64, dev, "K_hi")
+    _chk_n(n, 1, 17)
     N = 1 << n
+    _chk(q, torch.float64, dev, "q", N)
+    if pb > pa:
+        R = int(_ext.lib().bornvi_stein_sym_strip_rows())
+        _chk(K_lo, torch.float64, dev, "K_lo", (pb - pa) * R * N)
+        _chk(K_hi, torch.float64, dev, "K_hi", (pb - pa) * R * N)
     if out is None:
         out = torch.empty(N + 1, dtype=torch.float64, device=dev)
+    else:
+        _chk(out, torch.float64, dev, "out", N + 1)
     ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
     h.call("bornvi_stein_quadform_sym_pairs", n, _ptr(K_lo) if pb > pa else None, _ptr(K_hi) if pb > pa else None,
            int(pa), int(pb), _ptr(q), C.c_void_p(out.data_ptr() + 8 * N), _ptr(out), _ptr(ws), ws.numel(),
@@ -291,11 +321,16 @@ def stein_quadform_rows(K_rows, r0, r1, q, n, out=None):
     the partial sum over them of q_i y_i (the message one rank contributes to the all-gather)."""
     dev = K_rows.device
     h = _ext.handle_for(dev)
-    _chk(K_rows, torch.float64, dev, "K_rows")
-    _chk(q, torch.float64, dev, "q")
+    _chk_n(n, 1, 17)
     nr = r1 - r0
+    if not (0 <= r0 <= r1 <= (1 << n)):
+        raise BornviError("stein_quadform_rows: row range out of bounds")
+    _chk(K_rows, torch.float64, dev, "K_rows", nr << n)
+    _chk(q, torch.float64, dev, "q", 1 << n)
     if out is None:
         out = torch.empty(nr + 1, dtype=torch.float64, device=dev)
+    else:
+        _chk(out, torch.float64, dev, "out", nr + 1)
     ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_workspace_bytes", n, 1), "qf")
     h.call("bornvi_stein_quadform_rows", n, _ptr(K_rows), int(r0), int(r1), _ptr(q), _ptr(out),
            C.c_void_p(out.data_ptr() + 8 * nr), _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
@@ -308,6 +343,9 @@ def stein_kp_pairs(n, length_scale, zi, zj, si, sj):
     for t, dt, nm in ((zi, torch.int64, "zi"), (zj, torch.int64, "zj"), (si, torch.float64, "si"), (sj, torch.float64, "sj")):
         _chk(t, dt, dev, nm)
     M = zi.numel()
+    _chk_n(n)
+    if zj.numel() != M or si.numel() != M * n or sj.numel() != M * n:
+        raise BornviError("stein_kp_pairs: zi, zj must be [M] and si, sj [M, n]")
     out = torch.empty(M, dtype=torch.float64, device=dev)
     h.call("bornvi_stein_kp_pairs", n, float(length_scale), M, _ptr(zi), _ptr(zj), _ptr(si), _ptr(sj), _ptr(out),
            _ext.stream_ptr(dev))
@@ -318,7 +356,10 @@ def stein_quadform(K, Q, n, want_y=True):
     """Q [B, 2^n] (or [2^n]) -> (ksd2 [B], Y [B, 2^n] or None)."""
     dev = K.device
     h = _ext.handle_for(dev)
-    _chk(K, torch.float64, dev, "K")
+    _chk_n(n, 1, 17)
+    _chk(K, torch.float64, dev, "K", 1 << (2 * n))
+    if Q.numel() % (1 << n):
+        raise BornviError("Q: element count is not a multiple of 2^n")
     Q2 = Q.reshape(-1, 1 << n)
     _chk(Q2, torch.float64, dev, "Q")
     B = Q2.shape[0]
@@ -334,8 +375,9 @@ def stein_quadform_sym(K, q, n):
     """(ksd2 [1], y = K q [2^n]) for a symmetric K (as built by stein_gram): reads the upper triangle only."""
     dev = K.device
     h = _ext.handle_for(dev)
-    _chk(K, torch.float64, dev, "K")
-    _chk(q, torch.float64, dev, "q")
+    _chk_n(n, 1, 17)
+    _chk(K, torch.float64, dev, "K", 1 << (2 * n))
+    _chk(q, torch.float64, dev, "q", 1 << n)
     y = torch.empty(1 << n, dtype=torch.float64, device=dev)
     ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
     ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
@@ -348,8 +390,9 @@ def stein_matvec_kron(S, q, n, length_scale=1.0):
     """Matrix-free (ksd2 [1], y = K_p q [2^n])."""
     dev = S.device
     h = _ext.handle_for(dev)
-    _chk(S, torch.float64, dev, "S")
-    _chk(q, torch.float64, dev, "q")
+    _chk_n(n)
+    _chk(S, torch.float64, dev, "S", n << n)
+    _chk(q, torch.float64, dev, "q", 1 << n)
     y = torch.empty(1 << n, dtype=torch.float64, device=dev)
     ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
     ws = _ws(dev, _cached_size(h, "bornvi_stein_matvec_kron_workspace_bytes", n), "kron")
@@ -362,6 +405,11 @@ def ksd_grad_finish(n, shifted, n_shift, y, ksd2, want_dldq=False):
     """-> (loss [1], grad [n_shift], dLdq [2^n] or None); see bornvi_ksd_grad_finish."""
     dev = y.device
     h = _ext.handle_for(dev)
+    _chk_n(n)
+    _chk(y, torch.float64, dev, "y", 1 << n)
+    _chk(ksd2, torch.float64, dev, "ksd2", 1)
+    if n_shift:
+        _chk(shifted, torch.float64, dev, "shifted", (2 * n_shift) << n)
     loss = torch.empty(1, dtype=torch.float64, device=dev)
     grad = torch.empty(n_shift, dtype=torch.float64, device=dev)
     dldq = torch.empty(1 << n, dtype=torch.float64, device=dev) if want_dldq else None

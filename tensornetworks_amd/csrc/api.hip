@@ -80,6 +80,24 @@ int fail(bornvi_handle h, int code, const std::string& msg) {
       return fail(h, BORNVI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
   } while (0)
 
+// Entry points run on the handle's device and leave the calling thread's current device as they found it (a process
+// may drive several GPUs through several handles, and torch tracks the current device itself).
+struct DeviceScope {
+  int prev = -1;
+  bool changed = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); changed = (err == hipSuccess); }
+  }
+  ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define DEVICE_SCOPE(h)                    \
+  DeviceScope dev_scope_((h)->device);     \
+  HIPCHK(h, dev_scope_.err)
+
 int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
   auto key = std::make_tuple(ansatz, n, layers);
   auto it = h->plans.find(key);
@@ -89,7 +107,7 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
   const bool ok = (ansatz == -1) ? make_kron_plan(n, h->opt, dp->plan, msg)
                                  : make_plan(ansatz, n, layers, h->opt, dp->plan, msg);
   if (!ok) return fail(h, BORNVI_ERR_UNSUPPORTED, msg);
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, hipMalloc((void**)&dp->d_words, dp->plan.words.size() * sizeof(uint32_t)));
   HIPCHK(h, hipMemcpy(dp->d_words, dp->plan.words.data(), dp->plan.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (dp->plan.lds_bytes() > h->max_lds_prepared) {
@@ -242,7 +260,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   const size_t state_bytes = align_up((size_t)bc_max * ((size_t)16 << n), 256);
   void* bufA = base + gates_bytes;
   void* bufB = base + gates_bytes + state_bytes;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   if (shift_mode && h->prefix_share && p.n_passes > 1 && dp->d_fast && h->fast_path && dp->fast_workgroups > 0 &&
       batch > include_base) {
     // parameter-shift batch with prefix sharing: [gates | stateA | stateB | trash row]; each chunk carries the
@@ -374,7 +392,7 @@ int bornvi_stream_create_cu_range(bornvi_handle h, int first_cu, int num_cus, bo
   if (!h || !out) return BORNVI_ERR_INVALID;
   *out = nullptr;
   if (first_cu < 0 || num_cus < 1 || first_cu + num_cus > h->num_cus) return fail(h, BORNVI_ERR_INVALID, "CU range out of bounds");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   std::vector<uint32_t> mask((size_t)(h->num_cus + 31) / 32, 0u);
   for (int c = first_cu; c < first_cu + num_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
   hipStream_t st = nullptr;
@@ -386,7 +404,7 @@ int bornvi_stream_create_cu_range(bornvi_handle h, int first_cu, int num_cus, bo
 int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
   if (!stream) return BORNVI_OK;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, hipStreamDestroy((hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -447,7 +465,7 @@ int bornvi_gate1q_apply(bornvi_handle h, int n, long long batch, double* state, 
   if (!h) return BORNVI_ERR_INVALID;
   if (!state || !U || n < 1 || n > 40 || wire < 0 || wire >= n || batch < 0) return fail(h, BORNVI_ERR_INVALID, "bad argument");
   if (batch == 0) return BORNVI_OK;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_gate1q(state, n, batch, wire, U, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -458,7 +476,7 @@ int bornvi_cnot_apply(bornvi_handle h, int n, long long batch, double* state, in
   if (!state || n < 2 || n > 40 || control < 0 || control >= n || target < 0 || target >= n || control == target || batch < 0)
     return fail(h, BORNVI_ERR_INVALID, "bad argument");
   if (batch == 0) return BORNVI_OK;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_cnot(state, n, batch, control, target, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -467,7 +485,7 @@ int bornvi_born_probs(bornvi_handle h, int n, long long batch, const double* sta
   if (!h) return BORNVI_ERR_INVALID;
   if (!state || !probs || n < 0 || n > 40 || batch < 0) return fail(h, BORNVI_ERR_INVALID, "bad argument");
   if (batch == 0) return BORNVI_OK;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_born_probs(state, probs, n, batch, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -478,7 +496,7 @@ int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, dou
   if (bn->num_nodes < 1 || bn->num_nodes > 64 || bn->max_parents < 1 || !bn->role || !bn->n_parents || !bn->parents ||
       !bn->cpt_off || !bn->cpt)
     return fail(h, BORNVI_ERR_INVALID, "bad network descriptor");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_score(*bn, n, S, pxz, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -490,7 +508,7 @@ int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, co
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17 (8 * 4^n bytes)");
   if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
   if (row_begin < 0 || row_end < row_begin || row_end > (1ll << n)) return fail(h, BORNVI_ERR_INVALID, "row range out of bounds");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_gram_build(n, length_scale, S, K_rows, row_begin, row_end, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -505,7 +523,7 @@ int bornvi_stein_kp_pairs(bornvi_handle h, int n, double length_scale, long long
   if (!h) return BORNVI_ERR_INVALID;
   if (n < 1 || n > 30 || M < 0 || (M > 0 && (!zi || !zj || !si || !sj || !out))) return fail(h, BORNVI_ERR_INVALID, "bad argument");
   if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_kp_pairs(n, length_scale, M, zi, zj, si, sj, out, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -525,7 +543,7 @@ int bornvi_stein_quadform_rows(bornvi_handle h, int n, const double* K_rows, lon
   if (row_begin < 0 || row_end < row_begin || row_end > (1ll << n)) return fail(h, BORNVI_ERR_INVALID, "row range out of bounds");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_workspace_bytes(h, n, 1))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_quadform(n, K_rows, row_begin, row_end, q, y_rows, ksd2_partial, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -537,7 +555,7 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_workspace_bytes(h, n, B))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   const long long N = 1ll << n;
   for (int b = 0; b < B; ++b)
     HIPCHK(h, launch_quadform(n, K, 0, N, Q + b * N, Y ? Y + b * N : nullptr, ksd2 + b, (double*)workspace, (hipStream_t)stream));
@@ -557,7 +575,7 @@ int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const dou
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_quadform_sym(n, K, q, y, ksd2, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -576,7 +594,7 @@ int bornvi_stein_quadform_sym_pairs(bornvi_handle h, int n, const double* K_lo, 
   if (pair_end > pair_begin && (!K_lo || !K_hi)) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_quadform_sym_pairs(n, K_lo, K_hi, pair_begin, pair_end, q, y_partial, ksd2_partial, (double*)workspace,
                                       (hipStream_t)stream));
   return BORNVI_OK;
@@ -613,7 +631,7 @@ int bornvi_stein_matvec_kron(bornvi_handle h, int n, double length_scale, const 
   void* Bf = base + 256 + 2 * stb;
   const int np = dp->plan.n_passes;
   double* partials = (double*)(base + 256 + (np >= 3 ? 3 : (np == 2 ? 2 : 1)) * stb);
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_kron_pack(n, length_scale, S, q, (double*)X, gate, st));
   // X -> (A -> B -> A ...) -> X : the last pass writes back into X (dead after pass 0; with a single
   // pass each workgroup owns a whole state and reads it completely before writing).
@@ -628,7 +646,7 @@ int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_
   if (!h) return BORNVI_ERR_INVALID;
   if (!y || !ksd2 || n < 1 || n > 30 || n_shift < 0 || (n_shift > 0 && (!shifted || !grad)))
     return fail(h, BORNVI_ERR_INVALID, "bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   hipStream_t st = (hipStream_t)stream;
   if (dLdq_out || loss_out) HIPCHK(h, launch_dldq(y, ksd2, n, dLdq_out, loss_out, st));
   HIPCHK(h, launch_shift_dot(shifted, n_shift, y, ksd2, n, grad, nullptr, st));
@@ -639,7 +657,7 @@ int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double m
                           float* total_norm, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
   if (P < 0 || (P > 0 && (!grad64 || !grad32)) || !total_norm || !(max_norm >= 0.0)) return fail(h, BORNVI_ERR_INVALID, "bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, nullptr, nullptr, (hipStream_t)stream));
   return BORNVI_OK;
 }
@@ -649,7 +667,7 @@ int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, do
   if (!h) return BORNVI_ERR_INVALID;
   if (P < 0 || (P > 0 && (!grad64 || !grad32)) || !total_norm || !loss || !found_inf || !(max_norm >= 0.0))
     return fail(h, BORNVI_ERR_INVALID, "bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, loss, found_inf, (hipStream_t)stream));
   return BORNVI_OK;
 }

@@ -550,8 +550,10 @@ __device__ __forceinline__ void stage_dispatch(uint32_t kind, double2* __restric
     BORNVI_STAGE_NG(1, 0)
     BORNVI_STAGE_NG(0, 1)
     BORNVI_STAGE_NG(1, 1)
-    default: break;
+    default: break;   // unreachable: build_fast_tables admits only plans whose kinds pass fast_stage_kind_supported
   }
+  static_assert(fast_stage_kind_supported(4u | 8u | 16u) && !fast_stage_kind_supported(5u) && !fast_stage_kind_supported(32u),
+                "the switch above and plan.hpp's fast_stage_kind_supported must list the same kinds");
 #undef BORNVI_STAGE_NG
 #undef BORNVI_STAGE
 }

@@ -838,6 +838,7 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
         for (uint32_t b = ng; b < 4; ++b)
           if (fi[b] != 0xffffu) { out.words.clear(); out.pass_off.clear(); return false; }
         FS[FS_KIND] = ng | ((sflags & STAGE_SIGN_PRE) ? 8u : 0u) | ((sflags & STAGE_SIGN_POST) ? 16u : 0u);
+        if (!fast_stage_kind_supported(FS[FS_KIND])) { out.words.clear(); out.pass_off.clear(); return false; }
       }
       for (int b = 0; b < 4; ++b) { FS[FS_RB + b] = S[16 + (1 << b)] << 4; FS[FS_WB + b] = S[32 + (1 << b)] << 4; }
       for (int j = 0; j < 16; ++j) {   // the slot offsets must be linear in the slot number

@@ -112,7 +112,7 @@ constexpr int SIGNQ_WORDS = 49;
 
 // LDS index swizzle shared by planner and kernel: xor-fold the upper nibbles into the low nibble.
 // Linear over GF(2), its own inverse, keeps bits >= 4.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BORNVI_HD __host__ __device__
 #else
 #define BORNVI_HD
@@ -175,6 +175,12 @@ struct Plan {
 enum FastHeader : int { FH_NSTAGES = 0, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_IN_TAB, FH_OUT_TAB,
                         FH_IN_BASIS = 8, FH_OUT_BASIS = 12, FH_WORDS = 16 };
 enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10, FS_WORDS = 16 };
+
+// The stage kinds circuit_pass_fast_kernel has a specialised body for (stage_dispatch's switch): 0..4 fused gates on
+// register bits 0..ng-1, with or without either CZ sign product.  A stage of any other kind would issue NO tile stores
+// and break the kernel's hand-counted vmcnt waits, so build_fast_tables refuses the whole plan instead (the generic
+// kernel then runs it).
+constexpr bool fast_stage_kind_supported(uint32_t kind) { return (kind & 7u) <= 4u && (kind >> 5) == 0u; }
 
 struct FastTables {
   std::vector<uint32_t> words;

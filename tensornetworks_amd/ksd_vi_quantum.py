@@ -70,7 +70,13 @@ class KSDVariationalInference:
         """Arguments up to `pytorch_device` are the reference's (ksd_vi_quantum.py:19-30).
         Keyword-only extras: gram_mode in {"auto", "dense", "kron"} (dense Gram matrix vs matrix-free
         Kronecker mat-vec; "auto" = dense up to n = 16); process_group = torch.distributed group over
-        which the parameter-shift circuits are sharded (None = default group if initialised)."""
+        which the parameter-shift circuits are sharded (None = default group if initialised;
+        paramshift_shard.SOLO = never shard)."""
+        if int(qbm_num_latent_vars) != len(latent_vars_names):
+            # the scores are [2^len(latent_vars_names), len(latent_vars_names)] while the circuit has
+            # qbm_num_latent_vars qubits: the device kernels would index one with the other's sizes
+            raise ValueError(f"qbm_num_latent_vars ({qbm_num_latent_vars}) must equal len(latent_vars_names) "
+                             f"({len(latent_vars_names)})")
         self.bn = bayesian_network
         self.latent_vars_names = latent_vars_names
         self.observed_vars_names = observed_vars_names
@@ -288,7 +294,8 @@ class KSDVariationalInference:
             # every rank adds its share of (K q, q.y); one all-reduce of 2^n + 1 doubles
             pa, pb, nlo = self._K_pairs
             msg = backend.stein_quadform_sym_pairs(self._K[:nlo], self._K[nlo:], pa, pb, q, n)
-            shard.all_reduce_sum(msg, self.process_group)
+            with self._timed("allreduce"):
+                shard.all_reduce_sum(msg, self.process_group)
             return msg[1 << n:], msg[: 1 << n]
         r0, r1 = self._K_rows
         if ws == 1:
@@ -303,7 +310,8 @@ class KSDVariationalInference:
         msg[: r1 - r0] = part[:-1]
         msg[chunk] = part[-1]
         full = torch.empty((ws, chunk + 1), dtype=torch.float64, device=q.device)
-        shard.all_gather_flat(full.view(-1), msg, self.process_group)
+        with self._timed("allreduce"):          # (an all-gather here: the row shard's exchange of K q rows)
+            shard.all_gather_flat(full.view(-1), msg, self.process_group)
         y = full[:, :chunk].reshape(-1)[: 1 << n].contiguous()
         ksd2 = full[:, chunk].sum().reshape(1)      # fixed rank order: identical on every rank
         return ksd2, y
@@ -390,7 +398,8 @@ class KSDVariationalInference:
             theta64.record_stream(aux)
         with self._timed("finish"):
             loss, grad_local, _ = backend.ksd_grad_finish(n, shifted, n_local, y, ksd2)
-            grad = shard.all_gather_grad(grad_local, P, self.process_group)
+            with self._timed("allgather"):
+                grad = shard.all_gather_grad(grad_local, P, self.process_group)
         return loss, grad, q
 
     def make_optimizer(self, lr_born_machine, num_epochs, use_lr_scheduler=True, optimizer_type="adam",

@@ -16,8 +16,13 @@ import torch
 import torch.distributed as dist
 
 
+SOLO = "solo"     # process_group value: never shard, even inside an initialised torch.distributed job
+
+
 def world(group=None):
-    """(rank, world_size) of `group`, or (0, 1) when torch.distributed is not initialised."""
+    """(rank, world_size) of `group`, or (0, 1) when torch.distributed is not initialised (or group is SOLO)."""
+    if isinstance(group, str) and group == SOLO:
+        return 0, 1
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1

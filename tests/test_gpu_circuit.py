@@ -356,3 +356,44 @@ def test_prefix_sharing_with_the_large_tile(be, dev):
     np.testing.assert_allclose(got[0], oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)
     t2 = th.copy(); t2[P - 1] -= np.pi / 2
     np.testing.assert_allclose(got[2 * P], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
+
+
+def test_config4_full_depth_n20_L8_against_c_port(be, dev):
+    """BASELINE config 4 at its REAL depth (n = 20, L = 8, hardware_efficient: P = 480, the planner's own 2^13-tile
+    multi-pass plan with its fast tables; reference circuit quantum_born_machine.py:58-87).  Base row and the shifted
+    rows of the first / last parameter and one in the middle, both signs, against the oracle's C port at 1e-9; every
+    row sums to 1; the full 961-row batch with prefix sharing on is bitwise the batch with it off."""
+    from oracle import cpu_port as cp
+    if not cp.available():
+        pytest.skip("oracle/_build/libcpu_port.so not built")
+    ansatz, n, L = "hardware_efficient", 20, 8
+    P = oc.num_params(ansatz, n, L)
+    assert P == 480
+    g = torch.Generator().manual_seed(0)
+    th = (0.1 * torch.randn(P, generator=g, dtype=torch.float32)).double().numpy()      # bench.py's theta0
+    tht = torch.as_tensor(th, device=dev)
+    picks = [0, P // 2 + 7, P - 1]
+    want_t = [th.copy()]
+    for p_ in picks:
+        for sgn in (+1, -1):
+            t2 = th.copy(); t2[p_] += sgn * np.pi / 2
+            want_t.append(t2)
+    want = cp.circuit_probs(ansatz, n, L, np.stack(want_t))
+    try:
+        be.set_option(dev, "prefix_share", 0)
+        full = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+        assert full.shape == (2 * P + 1, 1 << n)
+        sums = full.sum(dim=1)
+        assert float((sums - 1.0).abs().max()) < 1e-12
+        rows = [0] + [r for p_ in picks for r in (1 + 2 * p_, 2 + 2 * p_)]
+        got = full[rows].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-17)
+        # the single-parameter entry point gives the same rows (what one rank of W evaluates)
+        one = be.paramshift_probs(ansatz, n, L, tht, P - 1, P, include_base=False)
+        assert torch.equal(one, full[2 * P - 1:])
+        be.set_option(dev, "prefix_share", 1)
+        shared = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+        assert torch.equal(shared, full)
+    finally:
+        be.set_option(dev, "prefix_share", 0)
+        be.release_workspaces()

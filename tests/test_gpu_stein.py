@@ -233,3 +233,36 @@ def test_full_size_gram_properties(be, dev):
     pairs = be.stein_kp_pairs(n, 1.0, idx, jdx, S[idx].contiguous(), S[jdx].contiguous())
     assert (pairs - K[idx, jdx]).abs().max().item() <= 1e-13 * max(pairs.abs().max().item(), 1.0)
     assert torch.equal(K[idx, jdx], K[jdx, idx])
+
+
+def test_wrappers_refuse_wrong_sizes(dev):
+    """The C ABI takes raw pointers: the tensor wrappers check every element count the kernels will index and raise
+    BornviError instead of launching (an out-of-bounds device read otherwise)."""
+    from tensornetworks_amd import backend
+    from tensornetworks_amd._ext import BornviError
+    n = 6
+    N = 1 << n
+    S = torch.zeros((N, n), dtype=torch.float64, device=dev)
+    q = torch.full((N,), 1.0 / N, dtype=torch.float64, device=dev)
+    K = backend.stein_gram(S, n, 1.0)
+    bad_calls = [
+        lambda: backend.stein_gram(S[: N // 2].contiguous(), n, 1.0),                      # S of a smaller network
+        lambda: backend.stein_gram(S, n, 1.0, rows=(0, N + 1)),
+        lambda: backend.stein_quadform_sym(K[: N // 2].contiguous(), q, n),
+        lambda: backend.stein_quadform_sym(K, q[:-2].contiguous(), n),
+        lambda: backend.stein_quadform(K, q[:-1].contiguous(), n),
+        lambda: backend.stein_quadform_rows(K[:8].contiguous(), 0, 16, q, n),
+        lambda: backend.stein_quadform_rows(K[:8].contiguous(), 0, 8, q[:-1].contiguous(), n),
+        lambda: backend.stein_matvec_kron(S, q[:-1].contiguous(), n, 1.0),
+        lambda: backend.stein_matvec_kron(S[:, :-1].contiguous(), q, n, 1.0),
+        lambda: backend.ksd_grad_finish(n, torch.zeros((3, N), dtype=torch.float64, device=dev), 2, q, q[:1].contiguous()),
+        lambda: backend.ksd_grad_finish(n, torch.zeros((4, N), dtype=torch.float64, device=dev), 2, q[:-1].contiguous(), q[:1].contiguous()),
+        lambda: backend.paramshift_probs("basic", n, 2, torch.zeros(5, dtype=torch.float64, device=dev), 0, 1),
+        lambda: backend.paramshift_grad("basic", n, 2, torch.zeros(24, dtype=torch.float64, device=dev), q[:-1].contiguous(), 0, 1),
+    ]
+    for i, call in enumerate(bad_calls):
+        with pytest.raises(BornviError):
+            call()
+            pytest.fail(f"call {i} was executed")
+    ksd2, y = backend.stein_quadform_sym(K, q, n)             # the well-formed calls still run
+    assert y.shape == (N,) and ksd2.shape == (1,)

@@ -60,8 +60,11 @@ def test_five_epoch_trace_sprinkler(dev, device, optimizer_type):
 
 
 @pytest.mark.parametrize("ansatz,n,L,mode", [("hardware_efficient", 5, 2, "dense"), ("all_to_all", 5, 2, "kron"),
-                                              ("basic", 6, 2, "dense"), ("hardware_efficient", 8, 4, "kron")])
+                                              ("basic", 6, 2, "dense"), ("hardware_efficient", 8, 4, "kron"),
+                                              ("hardware_efficient", 8, 4, "dense"), ("hardware_efficient", 8, 4, "auto")])
 def test_step_matches_oracle_synthetic(dev, ansatz, n, L, mode):
+    """q, loss AND gradient of one step against the oracle, including BASELINE config 2 (n = 8, L = 4) in the `dense`
+    mode that `auto` picks there (reference epoch body ksd_vi_quantum.py:110-161)."""
     bn, lat, obs, x = synthetic_network(n, 0)
     vi = make_vi(bn, lat, obs, n, L, ansatz, "cuda:0", seed=3, gram_mode=mode)
     vi._prepare_stein(x)
@@ -71,9 +74,10 @@ def test_step_matches_oracle_synthetic(dev, ansatz, n, L, mode):
     K_o = os_.gram_closed_form(os_.score_matrix(bn, x, lat, obs), n)
     np.testing.assert_allclose(q.cpu().numpy(), q_o, rtol=1e-10, atol=1e-14)
     assert math.isclose(loss.item(), ok.ksd_loss(K_o, q_o), rel_tol=1e-9)
-    if n <= 6:
-        g_o = oc.paramshift_vjp(ansatz, n, L, th, ok.ksd_grad_q(K_o, q_o))
-        np.testing.assert_allclose(grad.cpu().numpy(), g_o, rtol=1e-7, atol=1e-9 * np.abs(g_o).max())
+    if mode == "auto":
+        assert vi._K is not None and vi._K.shape == (1 << n, 1 << n)         # auto = dense up to n = 16
+    g_o = oc.paramshift_vjp(ansatz, n, L, th, ok.ksd_grad_q(K_o, q_o))
+    np.testing.assert_allclose(grad.cpu().numpy(), g_o, rtol=1e-7, atol=1e-9 * np.abs(g_o).max())
 
 
 def test_autograd_path_equals_fused_path(dev):

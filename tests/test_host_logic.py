@@ -245,6 +245,12 @@ def test_c_port_matches_numpy_oracle():
     tp = th[0][:20].copy(); tp[3] -= np.pi / 2
     np.testing.assert_allclose(pr[4], oc.probs("basic", 5, 2, tp), atol=1e-15)
     assert pr.shape == (5, 32) and used >= 1
+    # matrix-free K_p q (the CPU baseline's contraction at n = 20) == dense closed form == NumPy Kronecker oracle
+    from oracle import stein as os_
+    yk, k2 = cp.kron_matvec(g["S"], q, 6, 1.0)
+    np.testing.assert_allclose(yk, g["K"] @ q, rtol=0, atol=1e-13 * np.abs(g["K"] @ q).max())
+    np.testing.assert_allclose(yk, os_.stein_matvec_kron(g["S"], q, 6, 1.0), rtol=0, atol=1e-13 * np.abs(yk).max())
+    assert abs(k2 - q @ g["K"] @ q) <= 1e-12 * abs(k2)
 
 
 def test_param_first_pass_from_plan_words():
@@ -280,3 +286,12 @@ def test_first_pass_rule_is_the_librarys():
         assert L_.bornvi_plan_param_first_pass(aid, n, L, 0, buf, P) == P
         assert list(buf) == _ext.plan_param_first_pass(_ext.plan_words(aid, n, L)).tolist()
     assert L_.bornvi_plan_param_first_pass(99, 8, 2, 0, None, 0) == -1
+
+
+def test_trainer_rejects_mismatched_latent_count():
+    """qbm_num_latent_vars != len(latent_vars_names) would make the device kernels read S [2^m, m] as [2^n, n]
+    (an out-of-bounds read): refused in the constructor, before anything touches a device."""
+    from tensornetworks_amd.bayesian_network import get_sprinkler_network
+    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+    with pytest.raises(ValueError, match="must equal len"):
+        KSDVariationalInference(get_sprinkler_network(False), ['C', 'S', 'R'], ['W'], qbm_num_latent_vars=4)
