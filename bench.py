@@ -14,13 +14,19 @@ One step = one epoch body of ksd_vi_quantum.py:110-161 with TVD tracking off: ba
 KSD = sqrt(clamp(q^T K_p q)), dL/dq, 2P parameter-shift circuits -> grad, clip, Adam, scheduler.
 S and K_p are built once before the timed region (they do not depend on theta).
 
-N > 1 (strong scaling: the same step, split): the 2P shifted circuits and the rows of K_p are
-sharded over the ranks; two small all-gathers per step (K q rows, gradient scalars) over RCCL.
+Timing: W warm-up steps, then R repeats of EXACTLY K steps, each repeat bracketed by a barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over the ranks; `value` = K / median repeat
+(R >= 5 and R * K steps >= 2 s, so that a 2 % change can be ranked; min / max are reported beside it).
+
+N > 1 (strong scaling: the same step, split): the 2P shifted circuits are dealt to the ranks, the upper
+triangle of K_p is sharded in strip pairs; one all-reduce (K q) and one all-gather (gradient scalars) per
+step over RCCL.  `series` carries the same measurement for BASELINE config 4 (n = 20, L = 8, matrix-free
+contraction), the parameter-shift shard the >= 3.5x-at-8-GPUs target is quoted on.
 """
 import argparse
-import contextlib
-import io
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -29,9 +35,11 @@ import numpy as np
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, REPO)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64, dense
 
 WORKLOADS = {
     # name: (n, layers, ansatz, gram_mode)
@@ -41,10 +49,51 @@ WORKLOADS = {
     "n20_L8_kron": (20, 8, "hardware_efficient", "kron"),
     "n12_L4_dense": (12, 4, "hardware_efficient", "dense"),
 }
+SERIES_WORKLOAD = "n20_L8_kron"     # BASELINE config 4: reported beside the headline at every N
 
 
 def mean_ms(pairs):
     return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
+
+
+class Dist:
+    """The torch.distributed facts bench.py needs (rank 0 / world 1 when the job is a single process)."""
+
+    def __init__(self, dev):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.backend = os.environ.get("BORNVI_DIST_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing one GPU
+        self.dev = dev
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([value], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
 
 def gate_apply_microbench(dev, n=16, total_bytes=4 << 30, reps=20, warm=5):
@@ -77,42 +126,355 @@ def gate_apply_microbench(dev, n=16, total_bytes=4 << 30, reps=20, warm=5):
     return out
 
 
-def cpu_baseline(n, layers, ansatz, S_host, theta64, total_circuits):
-    """The oracle's C port (oracle/cpu_port.c, OpenMP) on the host cores, on a bounded sample of the
-    same step, extrapolated linearly in circuits and Gram rows.  A reported baseline, not a target."""
+def b2_pennylane(ansatz, n, layers, theta64):
+    """BASELINE.md B2 (opportunistic): PennyLane default.qubit + parameter-shift driven by this build's own circuit
+    definition, if PennyLane happens to be importable on the box.  It is not installed in this image and nothing here
+    tries to obtain it."""
+    try:
+        import pennylane as qml
+    except Exception:
+        print("[bench] PennyLane unavailable -- B1 reported", file=sys.stderr)
+        return "PennyLane unavailable -- B1 reported"
+    try:
+        from oracle import circuit as oc
+        gl = oc.gate_list(ansatz, n, layers)
+        dev = qml.device("default.qubit", wires=n, shots=None)
+
+        @qml.qnode(dev, interface="torch", diff_method="parameter-shift")
+        def pqc(w):
+            for kind, wires, p in gl:
+                if kind == "H":
+                    qml.Hadamard(wires=wires[0])
+                elif kind in ("RX", "RY", "RZ"):
+                    getattr(qml, kind)(w[p], wires=wires[0])
+                elif kind == "CNOT":
+                    qml.CNOT(wires=list(wires))
+                else:
+                    qml.CZ(wires=list(wires))
+            return qml.probs(wires=range(n))
+        w = torch.tensor(theta64, dtype=torch.float64, requires_grad=True)
+        t0 = time.perf_counter()
+        q = pqc(w)
+        t_fwd = time.perf_counter() - t0
+        return {"forward_seconds": round(t_fwd, 4), "sum_q": float(q.sum()),
+                "note": "one default.qubit forward; 2P parameter-shift evaluations cost about 2P times this"}
+    except Exception as e:       # a PennyLane of an unknown version: report, never fail the bench
+        return f"PennyLane importable but the B2 leg failed: {type(e).__name__}: {e}"
+
+
+def cpu_baseline(n, layers, ansatz, gram_mode, S_host, theta64):
+    """ONE full KSD-gradient step of the oracle's C port (oracle/cpu_port.c, OpenMP) on the host cores: all 2P + 1
+    circuits, then the contraction in the same form the GPU leg uses -- dense: y = K_p q over the whole 2^n x 2^n matrix,
+    streamed in freshly built 8 GiB row blocks (building K_p is outside the step, as on the GPU); kron: the matrix-free
+    Kronecker mat-vec.  No extrapolation.  A reported baseline, not a target."""
     from oracle import cpu_port as cp
     if not cp.available():
         return None
-    T = cp.max_threads()
+    N = 1 << n
     P = theta64.size
-    npar = max(1, min(P, 2 * T))
+    # un-timed warm-up of the port's OpenMP thread pool (its first parallel region in a process that has torch's own
+    # OpenMP runtime loaded takes ~1 s)
+    cp.circuit_probs("basic", 4, 1, np.zeros((2 * cp.max_threads(), 8)))
+    cp.kron_matvec(np.zeros((64, 6)), np.full(64, 1.0 / 64), 6, 1.0)
     t0 = time.perf_counter()
-    probs, used = cp.paramshift_probs(ansatz, n, layers, theta64, 0, npar, include_base=True)
+    probs, used = cp.paramshift_probs(ansatz, n, layers, theta64, 0, P, include_base=True)
     t_circ = time.perf_counter() - t0
-    n_circ = probs.shape[0]
-    rows = min(1 << n, 1024)
-    K_rows = cp.gram_rows(S_host, n, 1.0, 0, rows)            # building K is outside the step
     q = np.ascontiguousarray(probs[0])
-    cp.gemv_rows(K_rows, n, 0, rows, q)                         # warm
-    t_gemv = float("inf")                                       # best of 7: the 0.5 ms sample is at the mercy of one
-    for _ in range(7):                                          # descheduled OpenMP thread (seen: 30 ms once)
-        t0 = time.perf_counter()
-        cp.gemv_rows(K_rows, n, 0, rows, q)
-        t_gemv = min(t_gemv, time.perf_counter() - t0)
-    step_s = t_circ * total_circuits / n_circ + t_gemv * (1 << n) / rows
+    shifted = probs[1:]
+    if gram_mode == "dense":
+        rows_blk = max(1, min(N, (8 << 30) // (8 * N)))
+        y = np.empty(N)
+        t_gemv, t_build = 0.0, 0.0
+        for r0 in range(0, N, rows_blk):
+            r1 = min(N, r0 + rows_blk)
+            tb = time.perf_counter()
+            K_rows = cp.gram_rows(S_host, n, 1.0, r0, r1)        # outside the step (theta-independent)
+            t_build += time.perf_counter() - tb
+            tg = time.perf_counter()
+            y[r0:r1], _ = cp.gemv_rows(K_rows, n, r0, r1, q)
+            t_gemv += time.perf_counter() - tg
+            del K_rows
+        form = f"dense GEMV over all {N} rows in {rows_blk}-row blocks ({t_gemv * 1e3:.1f} ms; K_p build {t_build:.1f} s not counted)"
+    else:
+        t_gemv = float("inf")
+        for _ in range(3):
+            tg = time.perf_counter()
+            y, _ = cp.kron_matvec(S_host, q, n, 1.0)
+            t_gemv = min(t_gemv, time.perf_counter() - tg)
+        form = f"Kronecker mat-vec (best of 3: {t_gemv * 1e3:.1f} ms)"
+    tf = time.perf_counter()
+    ksd2 = float(q @ y)
+    loss = math.sqrt(max(ksd2, 1e-12))
+    grad = 0.5 * ((shifted[0::2] - shifted[1::2]) @ (y / loss))
+    t_fin = time.perf_counter() - tf
+    step_s = t_circ + t_gemv + t_fin
     return {"value": round(1.0 / step_s, 6), "unit": "steps/s", "cores": int(used), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{n_circ} of {total_circuits} circuits ({t_circ:.2f} s) + {rows} of {1 << n} Gram rows GEMV "
-                      f"({t_gemv * 1e3:.1f} ms), oracle/cpu_port.c with OpenMP, extrapolated linearly",
-            "est_step_seconds": round(step_s, 3)}
+            "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+            "sample": f"one full step: {probs.shape[0]} circuits ({t_circ:.2f} s) + {form} + gradient dots "
+                      f"({t_fin * 1e3:.0f} ms), oracle/cpu_port.c with OpenMP, nothing extrapolated",
+            "step_seconds": round(step_s, 3), "loss": loss, "grad_norm": float(np.linalg.norm(grad)),
+            "b2_pennylane": b2_pennylane(ansatz, n, layers, theta64)}
 
 
-def main():
+def make_vi(workload, dev, process_group=None, overlap=0):
+    from tensornetworks_amd.bayesian_network import synthetic_network
+    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+    n, layers, ansatz, gram_mode = WORKLOADS[workload]
+    bn, lat, obs, x = synthetic_network(n, seed=0)
+    torch.manual_seed(0)
+    vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,
+                                 qbm_ansatz_type=ansatz, pytorch_device=str(dev), gram_mode=gram_mode,
+                                 process_group=process_group)
+    if overlap >= 0:
+        vi.overlap_streams = {0: False, 1: True, 2: "partition"}[overlap]
+    g = torch.Generator().manual_seed(0)
+    P = vi.born_machine.num_ansatz_params
+    with torch.no_grad():     # theta0 = 0.1 * randn(P) float32, `small_random` (quantum_born_machine.py:43-45)
+        vi.born_machine.theta.copy_((0.1 * torch.randn(P, generator=g, dtype=torch.float32)).to(dev))
+    return vi, x
+
+
+def run_repeat(vi, step_fn, opt_state, clip, K, D, dev):
+    """EXACTLY K steps between barrier + synchronize on both sides; MAX over the ranks of the elapsed seconds."""
+    params, opt, sched = opt_state
+    losses = []
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        losses.append(step_fn(params, opt, sched, clip)[0])
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    return D.max_over_ranks(time.perf_counter() - t0), losses
+
+
+def phase_means(timers):
+    return {k: round(mean_ms(v), 4) for k, v in (timers or {}).items()}
+
+
+def dist_selftest(dev, D):
+    """N > 1: the sharded step against an UN-sharded recomputation of the same step on every rank (n = 12, L = 4, dense
+    Gram): all-reduced K q and q^T K q, gathered gradient, loss; and every rank holds the same bits."""
+    from tensornetworks_amd import paramshift_shard as shard
+    vs, x = make_vi("n12_L4_dense", dev)                       # default process group: sharded
+    v1, _ = make_vi("n12_L4_dense", dev, process_group=shard.SOLO)
+    with torch.no_grad():
+        v1.born_machine.theta.copy_(vs.born_machine.theta)
+    vs._prepare_stein(x)
+    v1._prepare_stein(x)
+    ls, gs, qs = vs.ksd_and_grad()
+    l1, g1, q1 = v1.ksd_and_grad()
+    k2s, ys = vs._stein_contract(qs)
+    k21, y1 = v1._stein_contract(q1)
+    torch.cuda.synchronize(dev)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+    errs = {"max_rel_err_y": rel(ys, y1), "max_rel_err_ksd2": rel(k2s, k21), "max_rel_err_grad": rel(gs, g1),
+            "max_rel_err_loss": rel(ls, l1), "q_bits_equal": bool(torch.equal(qs, q1))}
+    # the same bits on every rank (identical optimiser updates need no broadcast): compare with rank 0's copy
+    mine = torch.cat([gs, ys, ls])
+    ref = mine.clone() if D.backend == "nccl" else mine.cpu().clone()
+    if D.world > 1:
+        D.dist.broadcast(ref, src=0)
+    same = bool(torch.equal(ref.cpu(), mine.cpu()))
+    allr = D.gather_objects({"rank": D.rank, **errs, "same_bits_as_rank0": same})
+    ok = all(r["same_bits_as_rank0"] and r["q_bits_equal"] and r["max_rel_err_y"] < 1e-12 and r["max_rel_err_grad"] < 1e-10
+             and r["max_rel_err_loss"] < 1e-12 for r in allr)
+    out = {"ok": ok, "ranks": D.world, "workload": "n12_L4_dense", "strip_pair_shard": vs._K_pairs is not None,
+           "max_rel_err_y": max(r["max_rel_err_y"] for r in allr), "max_rel_err_grad": max(r["max_rel_err_grad"] for r in allr),
+           "max_rel_err_loss": max(r["max_rel_err_loss"] for r in allr), "per_rank": allr}
+    del vs, v1
+    torch.cuda.empty_cache()
+    if not ok:
+        raise SystemExit("bench.py --dist-selftest FAILED: " + json.dumps(out))
+    return out
+
+
+def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
+    """Builds the trainer for `workload`, runs warm-up + repeats; returns everything rank 0 needs for the record."""
+    from tensornetworks_amd import backend
+    n, layers, ansatz, gram_mode = WORKLOADS[workload]
+    vi, x = make_vi(workload, dev, overlap=args.overlap)
+    P = vi.born_machine.num_ansatz_params
+    theta0 = vi.born_machine.theta.detach().double().cpu().numpy()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    vi._prepare_stein(x)
+    torch.cuda.synchronize(dev)
+    precompute_s = time.perf_counter() - t0
+    if args.overlap < 0:
+        vi.choose_overlap()
+    opt_state = vi.make_optimizer(0.005, warmup + steps * 64, True, "adam", (0.9, 0.999))
+    clip = 10.0
+    # --host-sync 1: every step ends with loss.item() like the reference's epoch (the GPU idles while the host
+    # handles it); 0 (default): the same steps with the read-back of the K losses deferred to the end of the repeat
+    # (NaN/Inf guard on the device), so the K steps run back to back
+    step_fn = vi.training_step if args.host_sync else vi.training_step_async
+    losses = []
+    for _ in range(warmup):
+        losses.append(step_fn(*opt_state, clip)[0])
+    vi.timers = {}
+    elapsed = []
+    first, ls = run_repeat(vi, step_fn, opt_state, clip, steps, D, dev)
+    elapsed.append(first)
+    losses += ls
+    R = repeats if repeats > 0 else int(min(50, max(5, math.ceil(2.0 / max(first, 1e-6)))))
+    for _ in range(R - 1):
+        e, ls = run_repeat(vi, step_fn, opt_state, clip, steps, D, dev)
+        elapsed.append(e)
+        losses += ls
+    timers = vi.timers
+    vi.timers = None
+    # labelled extra: the same K steps with the other setting of prefix sharing (bit-identical shifted distributions,
+    # fewer circuit-passes); not part of `value`
+    extra_share = None
+    if want_extras:
+        backend.set_option(dev, "prefix_share", 0 if args.prefix_share else 1)
+        for _ in range(2):
+            step_fn(*opt_state, clip)
+        vi.timers = {}
+        e2, _ = run_repeat(vi, step_fn, opt_state, clip, steps, D, dev)
+        extra_share = {"prefix_share": 0 if args.prefix_share else 1, "steps_per_sec": round(steps / e2, 4),
+                       "ms_per_step": round(1e3 * e2 / steps, 4), "circuits_ms": round(mean_ms(vi.timers.get("circuits")), 4),
+                       "note": "same step with prefix sharing of the parameter-shift batch switched "
+                               + ("off" if args.prefix_share else "on") + " (opt-in, bornvi_set_option prefix_share): a shifted "
+                               "circuit starts from the base circuit's state at the first pass its parameter touches; rows bit-identical"}
+        vi.timers = None
+        backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
+    return {"vi": vi, "P": P, "theta0": theta0, "elapsed": elapsed, "timers": timers, "losses": losses,
+            "precompute_s": precompute_s, "extra_share": extra_share, "n": n, "layers": layers, "ansatz": ansatz,
+            "gram_mode": gram_mode}
+
+
+def pmc_traffic(workload, passes, tile_bits):
+    """Measured HBM bytes per launch from a rocprofv3 --pmc run of THIS plan (tools/pmc_traffic.sh + pmc_summarize.py),
+    newest matching file under profiles/; a file whose recorded plan signature differs is ignored."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_traffic_{workload}.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        sig = d.get("signature")
+        if sig and (sig.get("passes"), sig.get("tile_bits")) == (passes, tile_bits):
+            best = (f, d)
+    if best is None:
+        return {}, None
+    f, d = best
+    src = f"{os.path.relpath(f, REPO)} (builder's rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE run, commit {d['signature'].get('commit', '?')}; " \
+          "not measured in this run)"
+    return d["kernels"], src
+
+
+def kernel_table(m, D, args):
+    """Per-kernel roofline rows from the live event spans of the timed region.  ALGORITHMIC bytes per launch = what the
+    kernel's own algorithm has to move through HBM:
+      circuit pass: every state of the batch in (16 * 2^n; none in the first pass) and out (16 * 2^n, or 8 * 2^n
+                    probabilities in the last pass); the SURVEY 8(d) UN-FUSED accounting (32 * 2^n per gate per state)
+                    is reported beside it as `survey_8d_unfused_equivalent_gbs`
+      contraction:  dense: the upper triangle of K_p, 4 * 2^n * (2^n + 32) bytes per GPU share (SURVEY 8(d) counts the
+                    full matrix, 8 * 4^n: `survey_8d_full_matrix_gbs`), or the rank's rows for the row shard;
+                    kron: pack + the passes the Kronecker plan RUNS (each moves its (n+2)//2 packed states in and
+                    out) + combine."""
+    from tensornetworks_amd import _ext
+    vi, P, n, layers, ansatz, gram_mode = m["vi"], m["P"], m["n"], m["layers"], m["ansatz"], m["gram_mode"]
+    world = D.world
+    timers = m["timers"]
+    plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)   # same defaults as the handle
+    n_passes, n_gates = int(plan[3]), int(plan[11])
+    circuits_rank = 1 + 2 * len(range(0, P, world))            # rank 0: the parameters 0, W, 2W, ...
+    circ_ms, stein_ms, fin_ms = mean_ms(timers.get("circuits")), mean_ms(timers.get("stein")), mean_ms(timers.get("finish"))
+    base_ms = mean_ms(timers.get("base_circuit"))     # > 0 only in overlap mode: base circuit launched separately
+    circ_launches = n_passes * (2 if base_ms > 0 else 1)
+    circ_kernel_ms = circ_ms + base_ms
+    N = 1 << n
+    unfused_bytes = 32.0 * N * n_gates * circuits_rank
+    first_pass = _ext.plan_param_first_pass(plan)[list(range(0, P, world))] if n_passes > 1 else None
+    share_on = n_passes > 1 and bool(args.prefix_share)
+    active = [1 + 2 * int((first_pass <= i).sum()) if share_on else circuits_rank for i in range(n_passes)] if n_passes > 1 else [circuits_rank]
+    circ_bytes = sum(a * ((16.0 * N if i > 0 else 0.0) + (16.0 * N if i < n_passes - 1 else 8.0 * N)) for i, a in enumerate(active))
+    rows_rank = -(-N // world)
+    sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
+    stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
+    full_bytes = 8.0 * N * rows_rank
+    stein_launches = 1
+    stein_note = None
+    if gram_mode != "dense":
+        kplan = _ext.plan_words(-1, n, 0, args.tile_bits)
+        kpasses = int(kplan[3])
+        npk = (n + 2) // 2                                   # real vectors packed two per complex state
+        pack_b = 8.0 * N * n + 8.0 * N + 16.0 * N * npk
+        pass_b = kpasses * 32.0 * N * npk
+        comb_b = 16.0 * N * npk + 8.0 * N * n + 16.0 * N
+        stein_bytes = pack_b + pass_b + comb_b
+        stein_launches = kpasses + 2
+        stein_note = (f"matrix-free K_p q: pack ({pack_b / 1e6:.0f} MB) + {kpasses} fused passes over {npk} packed states "
+                      f"({pass_b / 1e6:.0f} MB: 32 * 2^n * {npk} per pass) + combine ({comb_b / 1e6:.0f} MB); ms spans all of them")
+    elif sym:
+        stein_bytes = 4.0 * N * (N + 32) / world
+        stein_note = ("K_p is bitwise symmetric: only its upper triangle is read (algorithmic bytes = 4 * 2^n * (2^n + 32)); "
+                      "ms includes the column-partial reduce and the final sum")
+    else:
+        stein_bytes = full_bytes
+    pmc, pmc_src = ({}, None)
+    if world == 1 and not args.prefix_share:
+        pmc, pmc_src = pmc_traffic(args.workload if m.get("is_main") else "", n_passes, int(plan[2]))
+    t_circ = next((kv.get("hbm_bytes_per_launch") for kname, kv in pmc.items() if kname.startswith("circuit_pass")), None)
+    t_stein = None
+    if sym:
+        parts = [kv["hbm_bytes_per_launch"] for kname, kv in pmc.items() if kname.startswith("quadform_sym")]
+        t_stein = sum(parts) if parts else None
+    kern = {
+        "circuit_pass_kernel": {"bound": "hbm", "launches_per_step": circ_launches,
+                                "achieved": round(circ_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_kernel_ms, 4),
+                                "avg_launch_ms": round(circ_kernel_ms / circ_launches, 4),
+                                "algorithmic_bytes_per_launch": circ_bytes / circ_launches, "traffic": t_circ,
+                                "traffic_source": pmc_src if t_circ else None,
+                                "circuit_passes_run": sum(active), "circuit_passes_without_prefix_sharing": circuits_rank * n_passes,
+                                "survey_8d_unfused_equivalent_gbs": round(unfused_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
+                                "note": "fused LDS-tiled engine: algorithmic bytes = each state read and written once per pass; "
+                                        "the same work as un-fused gate-apply (SURVEY 8(d): 32 * 2^n bytes per gate per state) "
+                                        "would need the survey_8d_unfused_equivalent_gbs rate"},
+        stein_name: {
+            "bound": "hbm", "launches_per_step": stein_launches,
+            "achieved": round(stein_bytes / (stein_ms * 1e-3) / 1e9, 1) if stein_ms else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(stein_ms, 4),
+            "avg_launch_ms": round(stein_ms, 4), "algorithmic_bytes_per_launch": stein_bytes, "traffic": t_stein,
+            "traffic_source": pmc_src if t_stein else None,
+            "survey_8d_full_matrix_gbs": round(full_bytes / (stein_ms * 1e-3) / 1e9, 1) if (sym and stein_ms) else None,
+            "note": stein_note},
+    }
+    for v in kern.values():
+        v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
+        if v["traffic"] and v["ms_per_step"]:
+            per_step = v["traffic"] * (v["launches_per_step"] if v is kern["circuit_pass_kernel"] else 1)
+            v["traffic_gbs"] = round(per_step / (v["ms_per_step"] * 1e-3) / 1e9, 1)
+            v["traffic_frac"] = round(v["traffic_gbs"] / v["peak"], 4)
+    config = {"n_qubits": n, "layers": layers, "ansatz": ansatz, "params": P, "circuits_per_step": 1 + 2 * P,
+              "gates_per_circuit": n_gates, "gram": gram_mode, "tile_bits": int(plan[2]), "passes": n_passes}
+    phases = {"circuits": round(circ_ms, 4), "base_circuit": round(base_ms, 4), "stein": round(stein_ms, 4),
+              "finish": round(fin_ms, 4), "allreduce": round(mean_ms(timers.get("allreduce")), 4),
+              "allgather": round(mean_ms(timers.get("allgather")), 4)}
+    return kern, config, phases
+
+
+def summarize(m, steps):
+    per = sorted(1e3 * e / steps for e in m["elapsed"])
+    med = float(np.median(per))
+    return med, {"n": len(per), "steps_each": steps, "ms_per_step_median": round(med, 4), "ms_per_step_min": round(per[0], 4),
+                 "ms_per_step_max": round(per[-1], 4), "timed_seconds_total": round(float(sum(m["elapsed"])), 3)}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the K timed steps (0 = at least 5 and at least 2 s in all)")
     ap.add_argument("--workload", default="n16_L6_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--series", default="auto", help="'auto': also measure n20_L8_kron (BASELINE config 4) beside the default "
+                                                      "workload; 'none'; or a workload name")
+    ap.add_argument("--dist-selftest", action="store_true", help="N > 1: check the sharded step against an un-sharded recomputation first")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gate-bench", action="store_true")
     ap.add_argument("--tile-bits", type=int, default=0)
@@ -129,31 +491,20 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="how circuits and contraction share the GPU: 0 in sequence (default), 1 second plain stream, 2 two "
                          "CU-masked streams (half the CUs each), -1 measured choice between 0 and 2 (choose_overlap)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % ndev)     # (several ranks may share a GPU in a rehearsal)
     torch.cuda.set_device(dev)
-    import torch.distributed as dist
-    dist_backend = os.environ.get("BORNVI_DIST_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing one GPU
-    if world > 1:
-        if dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(dist_backend)
+    D = Dist(dev)
+    world, rank = D.world, D.rank
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
-    from tensornetworks_amd import backend, _ext
-    from tensornetworks_amd.bayesian_network import synthetic_network
-    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
-
-    n, layers, ansatz, gram_mode = WORKLOADS[args.workload]
+    from tensornetworks_amd import backend
     if args.tile_bits:
         backend.set_option(dev, "tile_bits", args.tile_bits)
     if args.debug_flags:
@@ -168,198 +519,80 @@ def main():
     if args.fast_wgs_per_cu >= 0:
         backend.set_option(dev, "fast_workgroups_per_cu", args.fast_wgs_per_cu)
     backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
-    bn, lat, obs, x = synthetic_network(n, seed=0)
-    torch.manual_seed(0)
-    vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=layers,
-                                 qbm_ansatz_type=ansatz, pytorch_device=str(dev), gram_mode=gram_mode)
-    if args.overlap >= 0:
-        vi.overlap_streams = {0: False, 1: True, 2: "partition"}[args.overlap]
-    g = torch.Generator().manual_seed(0)
-    P = vi.born_machine.num_ansatz_params
-    with torch.no_grad():     # theta0 = 0.1 * randn(P) float32, `small_random` (quantum_born_machine.py:43-45)
-        vi.born_machine.theta.copy_((0.1 * torch.randn(P, generator=g, dtype=torch.float32)).to(dev))
-    theta0 = vi.born_machine.theta.detach().double().cpu().numpy()
 
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    vi._prepare_stein(x)
-    torch.cuda.synchronize(dev)
-    precompute_s = time.perf_counter() - t0
-    if args.overlap < 0:
-        vi.choose_overlap()
+    selftest = dist_selftest(dev, D) if (args.dist_selftest and world > 1) else None
 
-    total_steps = args.steps + args.warmup
-    params, opt, sched = vi.make_optimizer(0.005, total_steps, True, "adam", (0.9, 0.999))
-    clip = 10.0
-    # --host-sync 1: every step ends with loss.item() like the reference's epoch (the GPU idles while the host
-    # handles it); 0 (default): the same steps with the read-back of the K losses deferred to the end of the timed
-    # region (NaN/Inf guard on the device), so the K steps run back to back
-    step_fn = vi.training_step if args.host_sync else vi.training_step_async
-    losses = []
-    for _ in range(args.warmup):
-        losses.append(step_fn(params, opt, sched, clip)[0])
-
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    vi.timers = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses.append(step_fn(params, opt, sched, clip)[0])
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timers = vi.timers
-    vi.timers = None
-    # labelled extra: the same K steps with the other setting of prefix sharing (bit-identical shifted distributions,
-    # fewer circuit-passes); not part of `value`
-    extra_share = None
-    if not args.debug_flags and not args.no_extras:
-        backend.set_option(dev, "prefix_share", 0 if args.prefix_share else 1)
-        for _ in range(2):
-            step_fn(params, opt, sched, clip)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        vi.timers = {}
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_fn(params, opt, sched, clip)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        e2 = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([e2], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            e2 = float(tt.item())
-        extra_share = {"prefix_share": 0 if args.prefix_share else 1, "steps_per_sec": round(args.steps / e2, 4),
-                       "ms_per_step": round(1e3 * e2 / args.steps, 4), "circuits_ms": round(mean_ms(vi.timers.get("circuits")), 4),
-                       "note": "same step with prefix sharing of the parameter-shift batch switched "
-                               + ("off" if args.prefix_share else "on") + " (opt-in, bornvi_set_option prefix_share): a shifted "
-                               "circuit starts from the base circuit's state at the first pass its parameter touches; rows bit-identical"}
-        vi.timers = None
-        backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    m = measure(args.workload, dev, D, args, args.steps, args.warmup, args.repeats,
+                want_extras=not args.debug_flags and not args.no_extras)
+    m["is_main"] = True
+    kern, config, phases = kernel_table(m, D, args)
+    med_ms, rep = summarize(m, args.steps)
+    phases_per_rank = D.gather_objects({"rank": rank, **phases})
+    vi = m["vi"]
+    rec = None
     if rank == 0:
-        plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)   # same defaults as the handle
-        n_passes, n_gates = int(plan[3]), int(plan[11])
-        circuits_rank = 1 + 2 * len(range(0, P, world))            # rank 0: the parameters 0, W, 2W, ...
-        circ_ms, stein_ms, fin_ms = mean_ms(timers.get("circuits")), mean_ms(timers.get("stein")), mean_ms(timers.get("finish"))
-        base_ms = mean_ms(timers.get("base_circuit"))     # > 0 only in overlap mode: base circuit launched separately
-        circ_launches = n_passes * (2 if base_ms > 0 else 1)
-        circ_kernel_ms = circ_ms + base_ms
-        N = 1 << n
-        # ALGORITHMIC bytes per launch = what the kernel's own algorithm has to move through HBM:
-        #   circuit pass: every state of the batch in (16 * 2^n; none in the first pass) and out (16 * 2^n, or
-        #                 8 * 2^n probabilities in the last pass); the SURVEY 8(d) UN-FUSED accounting (32 * 2^n per
-        #                 gate per state) is reported beside it as `survey_8d_unfused_equivalent_gbs`
-        #   contraction:  the upper triangle of K_p, 4 * 2^n * (2^n + 32) bytes per GPU share (SURVEY 8(d) counts the
-        #                 full matrix, 8 * 4^n: `survey_8d_full_matrix_gbs`), or the rank's rows for the row shard
-        unfused_bytes = 32.0 * N * n_gates * circuits_rank
-        # prefix sharing: a shifted circuit joins the batch in the first pass its parameter touches (it reads the base
-        # circuit's state there), so pass i moves only the circuits already active
-        first_pass = _ext.plan_param_first_pass(plan)[list(range(0, P, world))] if n_passes > 1 else None
-        share_on = n_passes > 1 and bool(args.prefix_share)
-        active = [1 + 2 * int((first_pass <= i).sum()) if share_on else circuits_rank for i in range(n_passes)] if n_passes > 1 else [circuits_rank]
-        circ_bytes = sum(a * ((16.0 * N if i > 0 else 0.0) + (16.0 * N if i < n_passes - 1 else 8.0 * N)) for i, a in enumerate(active))
-        circuit_passes_run = sum(active)
-        rows_rank = -(-N // world)
-        sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
-        stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
-        full_bytes = 8.0 * N * rows_rank
-        if gram_mode != "dense":
-            stein_bytes = 16.0 * N * n * (n + 1)
-        elif sym:
-            stein_bytes = 4.0 * N * (N + 32) / world
-        else:
-            stein_bytes = full_bytes
-        # real HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.sh +
-        # tools/pmc_summarize.py), recorded for the default workload only
-        pmc = {}
-        pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic_n16_L6_dense.json")
-        if args.workload == "n16_L6_dense" and world == 1 and not args.tile_bits and os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))["kernels"]
-        t_circ = None
-        for kname, kv in pmc.items():
-            if kname.startswith("circuit_pass"):
-                t_circ = kv.get("hbm_bytes_per_launch")
-        t_stein = None
-        if sym and "quadform_sym_kernel" in pmc:
-            t_stein = pmc["quadform_sym_kernel"]["hbm_bytes_per_launch"] + pmc["quadform_sym_reduce_kernel"]["hbm_bytes_per_launch"]
-        kern = {
-            "circuit_pass_kernel": {"bound": "hbm", "launches_per_step": circ_launches,
-                                    "achieved": round(circ_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_kernel_ms, 4),
-                                    "avg_launch_ms": round(circ_kernel_ms / circ_launches, 4),
-                                    "algorithmic_bytes_per_launch": circ_bytes / circ_launches, "traffic": t_circ,
-                                    "circuit_passes_run": circuit_passes_run, "circuit_passes_without_prefix_sharing": circuits_rank * n_passes,
-                                    "survey_8d_unfused_equivalent_gbs": round(unfused_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
-                                    "note": "fused LDS-tiled engine: algorithmic bytes = each ACTIVE state read and written once per "
-                                            "pass (a shifted circuit starts from the base circuit's state at the first pass its parameter touches); traffic = measured HBM bytes per launch (PMC); the same work as un-fused "
-                                            "gate-apply (SURVEY 8(d): 32 * 2^n bytes per gate per state) would need the "
-                                            "survey_8d_unfused_equivalent_gbs rate"},
-            stein_name: {
-                "bound": "hbm", "launches_per_step": 1,
-                "achieved": round(stein_bytes / (stein_ms * 1e-3) / 1e9, 1) if stein_ms else None,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(stein_ms, 4),
-                "avg_launch_ms": round(stein_ms, 4), "algorithmic_bytes_per_launch": stein_bytes, "traffic": t_stein,
-                "survey_8d_full_matrix_gbs": round(full_bytes / (stein_ms * 1e-3) / 1e9, 1) if (sym and stein_ms) else None,
-                "note": ("K_p is bitwise symmetric: only its upper triangle is read (algorithmic bytes = 4 * 2^n * (2^n + 32)); "
-                         "ms includes the column-partial reduce and the final sum; traffic = measured HBM bytes (PMC)") if sym else None},
-        }
-        for v in kern.values():
-            v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
-            if v["traffic"] and v["ms_per_step"]:
-                per_step = v["traffic"] * v["launches_per_step"]
-                v["traffic_gbs"] = round(per_step / (v["ms_per_step"] * 1e-3) / 1e9, 1)
-                v["traffic_frac"] = round(v["traffic_gbs"] / v["peak"], 4)
         dom_name = max(kern, key=lambda k_: kern[k_]["ms_per_step"])
         roof = dict(kern[dom_name])
         roof["kernel"] = dom_name
-        value = args.steps / elapsed
+        value = 1e3 / med_ms
         rec = {
             "metric": "ksd_gradient_steps_per_sec", "value": round(value, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "ms_per_step": round(med_ms, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "n_qubits": n, "layers": layers, "ansatz": ansatz,
-                       "params": P, "circuits_per_step": 1 + 2 * P, "gates_per_circuit": n_gates,
-                       "gram": gram_mode, "bayesian_network": f"synthetic n={n} seed=0 (SURVEY 8d)",
+            "config": {"workload": args.workload, **config, "bayesian_network": f"synthetic n={m['n']} seed=0 (SURVEY 8d)",
                        "optimizer": "adam lr=0.005 cosine clip=10",
                        "parallelism": f"paramshift + gram {'strip-pair' if vi._K_pairs is not None else 'row'} shard x{world}",
-                       "dist_backend": dist_backend if world > 1 else None,
-                       "tile_bits": int(plan[2]), "passes": n_passes},
-            "roofline": roof, "kernels": kern, "extras": {"prefix_sharing": extra_share},
+                       "dist_backend": D.backend if world > 1 else None},
+            "repeats": rep, "roofline": roof, "kernels": kern, "extras": {"prefix_sharing": m["extra_share"]},
             "overlap": {"mode": {False: "sequential", True: "second stream", "partition": "cu-partition"}[vi.overlap_streams],
                         "measured_choice": vi.overlap_choice},
             "gram_placement": vi.gram_placement,
-            "phase_ms": {"circuits": round(circ_ms, 4), "base_circuit": round(base_ms, 4), "stein": round(stein_ms, 4),
-                         "finish": round(fin_ms, 4),
-                         "note": "event spans; with the contraction on a second stream the 'circuits' and "
-                                 "'base_circuit'+'stein' spans overlap in time" if base_ms > 0 else "event spans"},
-            "precompute_seconds": round(precompute_s, 3),
-            "host_sync": "per step (loss.item())" if args.host_sync else "deferred: K steps back to back, losses read after the timed region",
-            "loss_first_last": [float(losses[0]), float(losses[-1])],
+            "phase_ms": {**phases, "note": "event spans on the stream the kernels are launched on, mean over the timed region; "
+                                           "allreduce / allgather are inside stein / finish"},
+            "phase_ms_per_rank": phases_per_rank,
+            "precompute_seconds": round(m["precompute_s"], 3),
+            "host_sync": "per step (loss.item())" if args.host_sync else "deferred: K steps back to back, losses read after the repeat",
+            "loss_first_last": [float(m["losses"][0]), float(m["losses"][-1])],
         }
+        if selftest is not None:
+            rec["dist_selftest"] = selftest
+    S_host = vi._S.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    theta0, main_n = m["theta0"], m["n"]
+    main_cfg = (m["n"], m["layers"], m["ansatz"], m["gram_mode"])
+    del vi, m
+    backend.release_workspaces()
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE config 4 (n = 20, L = 8, matrix-free) beside the headline, same protocol, at every N ----
+    series_name = {"auto": SERIES_WORKLOAD if args.workload == "n16_L6_dense" else "none"}.get(args.series, args.series)
+    if series_name != "none" and not args.debug_flags:
+        if series_name not in WORKLOADS:
+            raise SystemExit(f"unknown --series workload {series_name}")
+        ks = max(3, min(args.steps, 10))
+        ms_ = measure(series_name, dev, D, args, ks, 2, 3, want_extras=False)
+        kern_s, config_s, phases_s = kernel_table(ms_, D, args)
+        med_s, rep_s = summarize(ms_, ks)
+        pr_s = D.gather_objects({"rank": rank, **phases_s})
+        if rank == 0:
+            rec["series"] = [{"workload": series_name, "metric": "ksd_gradient_steps_per_sec", "value": round(1e3 / med_s, 4),
+                              "unit": "steps/s", "n_gpus": world, "ms_per_step": round(med_s, 4), "repeats": rep_s,
+                              "config": config_s, "kernels": kern_s, "phase_ms": phases_s, "phase_ms_per_rank": pr_s,
+                              "scaling": "strong", "loss_first_last": [float(ms_["losses"][0]), float(ms_["losses"][-1])]}]
+        del ms_
+        backend.release_workspaces()
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_gate_bench:
-            vi._K = None
-            torch.cuda.empty_cache()
-            rec["gate_apply"] = gate_apply_microbench(dev, n=min(n, 16) if n >= 10 else 16)
+            rec["gate_apply"] = gate_apply_microbench(dev, n=min(main_n, 16) if main_n >= 10 else 16)
         if world == 1 and not args.no_cpu_baseline:
-            S_host = vi._S.cpu().numpy()
-            rec["cpu_baseline"] = cpu_baseline(n, layers, ansatz, S_host, theta0, 1 + 2 * P)
+            n_, layers_, ansatz_, gram_ = main_cfg
+            rec["cpu_baseline"] = cpu_baseline(n_, layers_, ansatz_, gram_, S_host, theta0)
             if rec["cpu_baseline"]:
-                rec["gpu_over_cpu"] = round(value / rec["cpu_baseline"]["value"], 1)
+                rec["gpu_over_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

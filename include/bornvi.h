@@ -161,6 +161,15 @@ int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, co
                                  long long row_begin, long long row_end, double* K_rows,
                                  bornvi_stream stream);
 
+/* Padded row pitch.  K_p with a power-of-two row pitch puts the same column of every row into the same HBM channel and
+ * bank, and the symmetric contraction streams 32 rows per wave at the same column; bornvi_stein_gram_ld(n) is the
+ * pitch (in doubles, >= 2^n, even) the library recommends: 2^n + 32 for n >= 12, else 2^n.  The `_ld` entry points
+ * take any even pitch in [2^n, 2^n + 4096]; columns >= 2^n of a row are never read or written. */
+long long bornvi_stein_gram_ld(int n);
+int bornvi_stein_gram_build_rows_ld(bornvi_handle h, int n, double length_scale, const double* S,
+                                    long long row_begin, long long row_end, double* K_rows, long long ld,
+                                    bornvi_stream stream);
+
 /* k_p(z_i, z_j | x) for M explicit pairs -- the batched form of ONE call of
  * stein_utils.get_stein_kernel_kp_value (:138-197): zi, zj dev int64 [M] outcome indices,
  * si, sj dev [M, n] the score rows sp_at_z1 / sp_at_z2 supplied by the caller, out dev [M]. */
@@ -184,6 +193,11 @@ int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const dou
                               double* ksd2, double* y, void* workspace, size_t workspace_bytes,
                               bornvi_stream stream);
 
+/* The same for a K with row pitch `ld` doubles (bornvi_stein_gram_build_rows_ld). */
+int bornvi_stein_quadform_sym_ld(bornvi_handle h, int n, const double* K, long long ld, const double* q,
+                                 double* ksd2, double* y, void* workspace, size_t workspace_bytes,
+                                 bornvi_stream stream);
+
 /* Strip-pair shard of the symmetric form (several GPUs, each reading only its part of the UPPER triangle).
  * The rows are cut into strips of bornvi_stein_sym_strip_rows() rows; pair p = strips p and n_strips-1-p (a long
  * and a short part of the triangle).  A GPU owning pairs [pair_begin, pair_end) holds K_lo = rows of the strips
@@ -196,6 +210,11 @@ int bornvi_stein_quadform_sym_pairs(bornvi_handle h, int n, const double* K_lo, 
                                     long long pair_begin, long long pair_end, const double* q,
                                     double* ksd2_partial, double* y_partial, void* workspace,
                                     size_t workspace_bytes, bornvi_stream stream);
+
+int bornvi_stein_quadform_sym_pairs_ld(bornvi_handle h, int n, const double* K_lo, const double* K_hi, long long ld,
+                                       long long pair_begin, long long pair_end, const double* q,
+                                       double* ksd2_partial, double* y_partial, void* workspace,
+                                       size_t workspace_bytes, bornvi_stream stream);
 
 /* Row-sharded form: K_rows holds rows [row_begin, row_end); q dev [2^n] (full);
  * y_rows dev [row_end - row_begin] = those rows of K q (or NULL); ksd2_partial dev [1] =

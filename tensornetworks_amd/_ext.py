@@ -59,6 +59,14 @@ _PROTOS = {
     "bornvi_stein_gram_build": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bornvi_stein_gram_build_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_longlong, C.c_longlong,
                                                C.c_void_p, C.c_void_p]),
+    "bornvi_stein_gram_ld": (C.c_longlong, [C.c_int]),
+    "bornvi_stein_gram_build_rows_ld": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_longlong, C.c_longlong,
+                                                  C.c_void_p, C.c_longlong, C.c_void_p]),
+    "bornvi_stein_quadform_sym_ld": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_stein_quadform_sym_pairs_ld": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong,
+                                                     C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                     C.c_void_p]),
     "bornvi_stein_quadform_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_stein_kp_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_longlong, C.c_void_p, C.c_void_p,

@@ -258,22 +258,47 @@ def score_from_packed(packed, n, dev):
     return S, pxz
 
 
-def stein_gram(S, n, length_scale=1.0, rows=None, out=None):
-    """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard); `out`:
-    a contiguous [rows, 2^n] float64 destination (e.g. a slice of a larger buffer)."""
+def gram_ld(n):
+    """Row pitch (doubles) the library recommends for a dense K_p that the symmetric contraction will stream:
+    2^n + 32 for n >= 12 (a power-of-two pitch makes the row streams of a strip collide on one HBM channel), else 2^n."""
+    return int(_ext.lib().bornvi_stein_gram_ld(int(n)))
+
+
+def _chk_matrix(K, rows, N, dev, name):
+    """K must be a float64 [rows, N] matrix on dev with unit column stride; returns its row pitch in doubles.  A padded
+    matrix is the [:, :N] view of a [rows, ld] buffer (what stein_gram(ld=...) returns)."""
+    if K.dtype != torch.float64 or K.device != dev or K.dim() != 2 or tuple(K.shape) != (int(rows), int(N)):
+        raise BornviError(f"{name}: expected float64 [{int(rows)}, {int(N)}] on {dev}, got {K.dtype} {tuple(K.shape)} on {K.device}")
+    if rows == 0:
+        return int(N)
+    ld = int(K.stride(0)) if rows > 1 else max(int(K.stride(0)), int(N))
+    if K.stride(1) != 1 or ld < N or (ld & 1 and N > 1):
+        raise BornviError(f"{name}: rows must be contiguous with an even pitch >= {int(N)} (strides {tuple(K.stride())})")
+    return ld
+
+
+def stein_gram(S, n, length_scale=1.0, rows=None, out=None, ld=None):
+    """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard).
+    ld: row pitch in doubles (default 2^n: a contiguous matrix; gram_ld(n) for the padded layout the symmetric
+    contraction streams best) -- the result is then the [:, :2^n] view of a [rows, ld] buffer.
+    out: a [rows, 2^n] float64 destination with unit column stride (e.g. rows of a larger, possibly padded, buffer)."""
     dev = S.device
     h = _ext.handle_for(dev)
     _chk_n(n, 1, 17)
+    N = 1 << n
     _chk(S, torch.float64, dev, "S", n << n)
-    r0, r1 = (0, 1 << n) if rows is None else (int(rows[0]), int(rows[1]))
-    if not (0 <= r0 <= r1 <= (1 << n)):
+    r0, r1 = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
+    if not (0 <= r0 <= r1 <= N):
         raise BornviError("stein_gram: row range out of bounds")
-    K = torch.empty((r1 - r0, 1 << n), dtype=torch.float64, device=dev) if out is None else out
-    if out is not None:
-        _chk(out, torch.float64, dev, "out")
-        if tuple(out.shape) != (r1 - r0, 1 << n):
-            raise _ext.BornviError("stein_gram: `out` must be [rows, 2^n]")
-    h.call("bornvi_stein_gram_build_rows", n, float(length_scale), _ptr(S), r0, r1, _ptr(K), _ext.stream_ptr(dev))
+    if out is None:
+        ld = N if ld is None else int(ld)
+        if ld < N or ld & 1 and N > 1:
+            raise BornviError("stein_gram: ld must be even and >= 2^n")
+        K = torch.empty((r1 - r0, ld), dtype=torch.float64, device=dev)[:, :N]
+    else:
+        K = out
+    pitch = _chk_matrix(K, r1 - r0, N, dev, "out" if out is not None else "K")
+    h.call("bornvi_stein_gram_build_rows_ld", n, float(length_scale), _ptr(S), r0, r1, _ptr(K), pitch, _ext.stream_ptr(dev))
     return K
 
 
@@ -301,17 +326,19 @@ def stein_quadform_sym_pairs(K_lo, K_hi, pa, pb, q, n, out=None):
     _chk_n(n, 1, 17)
     N = 1 << n
     _chk(q, torch.float64, dev, "q", N)
+    ld = N
     if pb > pa:
         R = int(_ext.lib().bornvi_stein_sym_strip_rows())
-        _chk(K_lo, torch.float64, dev, "K_lo", (pb - pa) * R * N)
-        _chk(K_hi, torch.float64, dev, "K_hi", (pb - pa) * R * N)
+        ld = _chk_matrix(K_lo, (pb - pa) * R, N, dev, "K_lo")
+        if _chk_matrix(K_hi, (pb - pa) * R, N, dev, "K_hi") != ld:
+            raise BornviError("K_lo and K_hi must have the same row pitch")
     if out is None:
         out = torch.empty(N + 1, dtype=torch.float64, device=dev)
     else:
         _chk(out, torch.float64, dev, "out", N + 1)
     ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
-    h.call("bornvi_stein_quadform_sym_pairs", n, _ptr(K_lo) if pb > pa else None, _ptr(K_hi) if pb > pa else None,
-           int(pa), int(pb), _ptr(q), C.c_void_p(out.data_ptr() + 8 * N), _ptr(out), _ptr(ws), ws.numel(),
+    h.call("bornvi_stein_quadform_sym_pairs_ld", n, _ptr(K_lo) if pb > pa else None, _ptr(K_hi) if pb > pa else None,
+           ld, int(pa), int(pb), _ptr(q), C.c_void_p(out.data_ptr() + 8 * N), _ptr(out), _ptr(ws), ws.numel(),
            _ext.stream_ptr(dev))
     return out
 
@@ -376,12 +403,12 @@ def stein_quadform_sym(K, q, n):
     dev = K.device
     h = _ext.handle_for(dev)
     _chk_n(n, 1, 17)
-    _chk(K, torch.float64, dev, "K", 1 << (2 * n))
+    ld = _chk_matrix(K, 1 << n, 1 << n, dev, "K")
     _chk(q, torch.float64, dev, "q", 1 << n)
     y = torch.empty(1 << n, dtype=torch.float64, device=dev)
     ksd2 = torch.empty(1, dtype=torch.float64, device=dev)
     ws = _ws(dev, _cached_size(h, "bornvi_stein_quadform_sym_workspace_bytes", n), "qfsym")
-    h.call("bornvi_stein_quadform_sym", n, _ptr(K), _ptr(q), _ptr(ksd2), _ptr(y), _ptr(ws), ws.numel(),
+    h.call("bornvi_stein_quadform_sym_ld", n, _ptr(K), ld, _ptr(q), _ptr(ksd2), _ptr(y), _ptr(ws), ws.numel(),
            _ext.stream_ptr(dev))
     return ksd2, y
 

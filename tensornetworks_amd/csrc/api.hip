@@ -297,6 +297,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
 }
 
 bool valid_n_for_dense(int n) { return n >= 1 && n <= 17; }
+bool valid_ld(int n, long long ld) { return ld >= (1ll << n) && (ld & 1) == 0 && ld <= (1ll << n) + 4096; }
 
 }  // namespace
 
@@ -501,16 +502,31 @@ int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, dou
   return BORNVI_OK;
 }
 
-int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,
-                                 long long row_end, double* K_rows, bornvi_stream stream) {
+long long bornvi_stein_gram_ld(int n) {
+  if (n < 1 || n > 17) return 0;
+  // Rows of a power-of-two pitch put the same column of every row into the same HBM channel and bank: the row streams
+  // of the symmetric contraction (32 per wave, all at the same column) then collide.  256 bytes of padding per row
+  // rotates consecutive rows over the channels.  Small matrices (a few MiB: cache-resident) stay dense.
+  return n >= 12 ? (1ll << n) + 32 : (1ll << n);
+}
+
+int bornvi_stein_gram_build_rows_ld(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,
+                                    long long row_end, double* K_rows, long long ld, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
   if (!S || (!K_rows && row_end > row_begin)) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17 (8 * 4^n bytes)");
   if (!(length_scale > 0.0)) return fail(h, BORNVI_ERR_INVALID, "length_scale must be positive");
   if (row_begin < 0 || row_end < row_begin || row_end > (1ll << n)) return fail(h, BORNVI_ERR_INVALID, "row range out of bounds");
+  if (!valid_ld(n, ld)) return fail(h, BORNVI_ERR_INVALID, "leading dimension must be even, >= 2^n and <= 2^n + 4096");
   DEVICE_SCOPE(h);
-  HIPCHK(h, launch_gram_build(n, length_scale, S, K_rows, row_begin, row_end, (hipStream_t)stream));
+  HIPCHK(h, launch_gram_build(n, length_scale, S, K_rows, row_begin, row_end, ld, (hipStream_t)stream));
   return BORNVI_OK;
+}
+
+int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,
+                                 long long row_end, double* K_rows, bornvi_stream stream) {
+  if (n < 0 || n > 40) return h ? fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17 (8 * 4^n bytes)") : BORNVI_ERR_INVALID;
+  return bornvi_stein_gram_build_rows_ld(h, n, length_scale, S, row_begin, row_end, K_rows, 1ll << n, stream);
 }
 
 int bornvi_stein_gram_build(bornvi_handle h, int n, double length_scale, const double* S, double* K, bornvi_stream stream) {
@@ -568,36 +584,54 @@ size_t bornvi_stein_quadform_sym_workspace_bytes(bornvi_handle h, int n) {
   return align_up(quadform_sym_workspace_doubles(n) * sizeof(double), 256);
 }
 
-int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const double* q, double* ksd2, double* y,
-                              void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+int bornvi_stein_quadform_sym_ld(bornvi_handle h, int n, const double* K, long long ld, const double* q, double* ksd2,
+                                 double* y, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
   if (!K || !q || !ksd2) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  if (!valid_ld(n, ld)) return fail(h, BORNVI_ERR_INVALID, "leading dimension must be even, >= 2^n and <= 2^n + 4096");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
+  if ((uintptr_t)K & 15) return fail(h, BORNVI_ERR_INVALID, "K must be 16-byte aligned");
   DEVICE_SCOPE(h);
-  HIPCHK(h, launch_quadform_sym(n, K, q, y, ksd2, (double*)workspace, (hipStream_t)stream));
+  HIPCHK(h, launch_quadform_sym(n, K, ld, q, y, ksd2, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;
+}
+
+int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const double* q, double* ksd2, double* y,
+                              void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (n < 0 || n > 40) return h ? fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17") : BORNVI_ERR_INVALID;
+  return bornvi_stein_quadform_sym_ld(h, n, K, 1ll << n, q, ksd2, y, workspace, workspace_bytes, stream);
 }
 
 int bornvi_stein_sym_strip_rows(void) { return quadform_sym_rows_per_strip(); }
 
-int bornvi_stein_quadform_sym_pairs(bornvi_handle h, int n, const double* K_lo, const double* K_hi, long long pair_begin,
-                                    long long pair_end, const double* q, double* ksd2_partial, double* y_partial,
-                                    void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+int bornvi_stein_quadform_sym_pairs_ld(bornvi_handle h, int n, const double* K_lo, const double* K_hi, long long ld,
+                                       long long pair_begin, long long pair_end, const double* q, double* ksd2_partial,
+                                       double* y_partial, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
   if (!q || !ksd2_partial || !y_partial) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  if (!valid_ld(n, ld)) return fail(h, BORNVI_ERR_INVALID, "leading dimension must be even, >= 2^n and <= 2^n + 4096");
   const long long N = 1ll << n, R = quadform_sym_rows_per_strip();
   const long long ns = (N + R - 1) / R, npairs = (ns + 1) / 2;
   if (pair_begin < 0 || pair_end < pair_begin || pair_end > npairs) return fail(h, BORNVI_ERR_INVALID, "strip-pair range out of bounds");
   if (pair_end > pair_begin && (!K_lo || !K_hi)) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (((uintptr_t)K_lo | (uintptr_t)K_hi) & 15) return fail(h, BORNVI_ERR_INVALID, "K blocks must be 16-byte aligned");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
   DEVICE_SCOPE(h);
-  HIPCHK(h, launch_quadform_sym_pairs(n, K_lo, K_hi, pair_begin, pair_end, q, y_partial, ksd2_partial, (double*)workspace,
+  HIPCHK(h, launch_quadform_sym_pairs(n, K_lo, K_hi, ld, pair_begin, pair_end, q, y_partial, ksd2_partial, (double*)workspace,
                                       (hipStream_t)stream));
   return BORNVI_OK;
+}
+
+int bornvi_stein_quadform_sym_pairs(bornvi_handle h, int n, const double* K_lo, const double* K_hi, long long pair_begin,
+                                    long long pair_end, const double* q, double* ksd2_partial, double* y_partial,
+                                    void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (n < 0 || n > 40) return h ? fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17") : BORNVI_ERR_INVALID;
+  return bornvi_stein_quadform_sym_pairs_ld(h, n, K_lo, K_hi, 1ll << n, pair_begin, pair_end, q, ksd2_partial, y_partial,
+                                            workspace, workspace_bytes, stream);
 }
 
 size_t bornvi_stein_matvec_kron_workspace_bytes(bornvi_handle h, int n) {

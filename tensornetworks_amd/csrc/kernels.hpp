@@ -41,18 +41,20 @@ hipError_t launch_dldq(const double* y, const double* ksd2, int n, double* dLdq,
 
 // ---- Stein ----------------------------------------------------------------------------------------
 hipError_t launch_score(const bornvi_bn_desc& bn, int n, double* S, double* pxz, hipStream_t st);
+// `ld`: row pitch of K in doubles (>= 2^n, even)
 hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, long long row_begin,
-                             long long row_end, hipStream_t st);
+                             long long row_end, long long ld, hipStream_t st);
 hipError_t launch_kp_pairs(int n, double length_scale, long long M, const long long* zi, const long long* zj,
                            const double* si, const double* sj, double* out, hipStream_t st);
 size_t quadform_partials(long long rows);  // number of per-workgroup partial sums
 hipError_t launch_quadform(int n, const double* K, long long row_begin, long long row_end, const double* q,
                            double* y_or_null, double* ksd2, double* partials, hipStream_t st);
 size_t quadform_sym_workspace_doubles(int n);
-hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2, double* ws,
-                               hipStream_t st);
-hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long pair_begin, long long pair_end,
-                                     const double* q, double* y_or_null, double* ksd2, double* ws, hipStream_t st);
+hipError_t launch_quadform_sym(int n, const double* K, long long ld, const double* q, double* y_or_null, double* ksd2,
+                               double* ws, hipStream_t st);
+hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long ld, long long pair_begin,
+                                     long long pair_end, const double* q, double* y_or_null, double* ksd2, double* ws,
+                                     hipStream_t st);
 int quadform_sym_rows_per_strip();
 // matrix-free mat-vec helpers
 hipError_t launch_kron_pack(int n, double length_scale, const double* S, const double* q,

@@ -80,7 +80,7 @@ struct PowTable { double v[33]; };
 template <int NB>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ S, double* __restrict__ K,
                                                    PowTable apow, double c_same, double dc,
-                                                   long long row_begin, long long row_end) {
+                                                   long long row_begin, long long row_end, long long ld) {
   const long long N = 1ll << NB;
   const long long j0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (j0 >= N) return;
@@ -114,17 +114,17 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ S,
       }
       out[c] = apow.v[__popc(x)] * (dot - c_same * (RTi + RTj[c]) - dc * ms);
     }
-    *reinterpret_cast<double2*>(K + (i - row_begin) * N + j0) = make_double2(out[0], out[1]);
+    *reinterpret_cast<double2*>(K + (i - row_begin) * ld + j0) = make_double2(out[0], out[1]);
   }
 }
 
 template <int NB>
 static hipError_t launch_gram_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc,
-                                 long long row_begin, long long row_end, hipStream_t st) {
+                                 long long row_begin, long long row_end, long long ld, hipStream_t st) {
   const long long N = 1ll << NB;
   if (row_end <= row_begin) return hipSuccess;
   dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)((row_end - row_begin + GRAM_ROWS - 1) / GRAM_ROWS));
-  gram_kernel<NB><<<grid, 256, 0, st>>>(S, K, apow, c_same, dc, row_begin, row_end);
+  gram_kernel<NB><<<grid, 256, 0, st>>>(S, K, apow, c_same, dc, row_begin, row_end, ld);
   return hipGetLastError();
 }
 
@@ -189,7 +189,7 @@ __device__ __forceinline__ void gram_factors(const double (&sv)[GM_MAXN], long l
 template <int n>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ S, double* __restrict__ K,
                                                         PowTable apow, double c_same, double dc, long long row_begin,
-                                                        long long row_end) {
+                                                        long long row_end, long long ld) {
   extern __shared__ double gm_lds[];
   __shared__ double apow_s[33];
   constexpr GramFactorPitch g = gram_pitch(n);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
       // D layout: row = (lane >> 4) + 4 r, col = lane & 15
       const long long ib = i_blk + it * 16 + ak;
       const double* al0 = Lt + (it * 16 + ak) * g.rowpitch + 3 * g.p;   // alpha of row ak + 4 r: + 4 r rowpitch
-      double* __restrict__ Kp = K + (ib - row_begin) * N + j;
+      double* __restrict__ Kp = K + (ib - row_begin) * ld + j;
       if (i_blk + GM_ROWS <= row_end) {     // whole row block inside the range (wave-uniform): no per-row tests
         double w0[4], w1[4], e0[4], e1[4];
 #pragma unroll
@@ -265,18 +265,18 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          __builtin_nontemporal_store(w0[r] * ((a1[r] + (a2[r] + a3[r])) + e0[r]), Kp + (long long)(4 * r) * N);
-          __builtin_nontemporal_store(w1[r] * ((c1[r] + (c2[r] + c3[r])) + e1[r]), Kp + (long long)(16 + 4 * r) * N);
+          __builtin_nontemporal_store(w0[r] * ((a1[r] + (a2[r] + a3[r])) + e0[r]), Kp + (long long)(4 * r) * ld);
+          __builtin_nontemporal_store(w1[r] * ((c1[r] + (c2[r] + c3[r])) + e1[r]), Kp + (long long)(16 + 4 * r) * ld);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const long long i = ib + 4 * r;
           if (i < row_end)
-            K[(i - row_begin) * N + j] = apow_s[__popcll((unsigned long long)(i ^ j))] *
+            K[(i - row_begin) * ld + j] = apow_s[__popcll((unsigned long long)(i ^ j))] *
                                          ((a1[r] + (a2[r] + a3[r])) + (al0[4 * r * g.rowpitch] + alpha_j));
           if (i + 16 < row_end)
-            K[(i + 16 - row_begin) * N + j] = apow_s[__popcll((unsigned long long)((i + 16) ^ j))] *
+            K[(i + 16 - row_begin) * ld + j] = apow_s[__popcll((unsigned long long)((i + 16) ^ j))] *
                                               ((c1[r] + (c2[r] + c3[r])) + (al0[(16 + 4 * r) * g.rowpitch] + alpha_j));
         }
       }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
 
 template <int NB>
 static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc,
-                                      long long row_begin, long long row_end, hipStream_t st) {
+                                      long long row_begin, long long row_end, long long ld, hipStream_t st) {
   const long long N = 1ll << NB;
   if (row_end <= row_begin) return hipSuccess;
   constexpr GramFactorPitch g = gram_pitch(NB);
@@ -300,14 +300,14 @@ static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable
   }
   const long long cols = N < GM_COLS ? N : GM_COLS;
   dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - row_begin + GM_ROWS - 1) / GM_ROWS));
-  gram_mfma_kernel<NB><<<grid, 256, lds, st>>>(S, K, apow, c_same, dc, row_begin, row_end);
+  gram_mfma_kernel<NB><<<grid, 256, lds, st>>>(S, K, apow, c_same, dc, row_begin, row_end, ld);
   return hipGetLastError();
 }
 
 static hipError_t launch_gram_mfma(int n, const double* S, double* K, const PowTable& apow, double c_same, double dc,
-                                   long long row_begin, long long row_end, hipStream_t st) {
+                                   long long row_begin, long long row_end, long long ld, hipStream_t st) {
   switch (n) {
-#define BORNVI_GM_CASE(NB) case NB: return launch_gram_mfma_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, st);
+#define BORNVI_GM_CASE(NB) case NB: return launch_gram_mfma_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, ld, st);
     BORNVI_GM_CASE(8) BORNVI_GM_CASE(9) BORNVI_GM_CASE(10) BORNVI_GM_CASE(11) BORNVI_GM_CASE(12) BORNVI_GM_CASE(13)
     BORNVI_GM_CASE(14) BORNVI_GM_CASE(15) BORNVI_GM_CASE(16) BORNVI_GM_CASE(17)
 #undef BORNVI_GM_CASE
@@ -316,7 +316,7 @@ static hipError_t launch_gram_mfma(int n, const double* S, double* K, const PowT
 }
 
 hipError_t launch_gram_build(int n, double length_scale, const double* S, double* K, long long row_begin,
-                             long long row_end, hipStream_t st) {
+                             long long row_end, long long ld, hipStream_t st) {
   PowTable apow;
   const double denom = (double)n * length_scale;
   for (int d = 0; d <= 32; ++d) apow.v[d] = std::exp(-(double)d / denom);  // stein_utils.py:55
@@ -325,9 +325,9 @@ hipError_t launch_gram_build(int n, double length_scale, const double* S, double
   const double dc = c_diff - c_same;
   // matrix-core path for n >= 8 (2^n >= 256: whole 16 x 16 tiles); BORNVI_GRAM_VALU=1 keeps the VALU kernel (A/B)
   static const bool force_valu = [] { const char* e = getenv("BORNVI_GRAM_VALU"); return e && e[0] == '1'; }();
-  if (n >= 8 && n <= GM_MAXN && !force_valu) return launch_gram_mfma(n, S, K, apow, c_same, dc, row_begin, row_end, st);
+  if (n >= 8 && n <= GM_MAXN && !force_valu) return launch_gram_mfma(n, S, K, apow, c_same, dc, row_begin, row_end, ld, st);
   switch (n) {
-#define BORNVI_GRAM_CASE(NB) case NB: return launch_gram_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, st);
+#define BORNVI_GRAM_CASE(NB) case NB: return launch_gram_nb<NB>(S, K, apow, c_same, dc, row_begin, row_end, ld, st);
     BORNVI_GRAM_CASE(1) BORNVI_GRAM_CASE(2) BORNVI_GRAM_CASE(3) BORNVI_GRAM_CASE(4) BORNVI_GRAM_CASE(5)
     BORNVI_GRAM_CASE(6) BORNVI_GRAM_CASE(7) BORNVI_GRAM_CASE(8) BORNVI_GRAM_CASE(9) BORNVI_GRAM_CASE(10)
     BORNVI_GRAM_CASE(11) BORNVI_GRAM_CASE(12) BORNVI_GRAM_CASE(13) BORNVI_GRAM_CASE(14) BORNVI_GRAM_CASE(15)
@@ -477,139 +477,127 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 // then y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j] in a second kernel.  No atomics: fixed summation order.
 // Traffic: 8 * N^2 / 2 (+ one diagonal block per strip) + 2 * 8 * N^2 / (2 SYM_ROWS) bytes.
 // ------------------------------------------------------------------------------------------------
-constexpr int SYM_ROWS = 32;
+#ifndef BORNVI_SYM_ROWS
+#define BORNVI_SYM_ROWS 32
+#endif
+constexpr int SYM_ROWS = BORNVI_SYM_ROWS;
 #ifndef BORNVI_SYM_RB
 #define BORNVI_SYM_RB 8
 #define BORNVI_SYM_CH 4
 #endif
 constexpr int SYM_RB = BORNVI_SYM_RB, SYM_CH = BORNVI_SYM_CH;   // wide loop: SYM_RB rows x SYM_CH 1-KiB chunks per row in flight
 constexpr int SYM_MAX_PARTS = 16;   // column pieces per strip (row-partial buffers in the workspace)
+typedef double sym_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int sym_u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
   return s * N - (long long)SYM_ROWS * (s * (s + 1) / 2);   // Z_s[j - (s+1) SYM_ROWS] lives at this base
 }
 
-// one strip: rows [s SYM_ROWS, (s+1) SYM_ROWS), columns >= s SYM_ROWS
+// 16 bytes through the strip's buffer descriptor: address = base + voff (per lane: row and lane part, loop-invariant)
+// + soff (wave-uniform: the column position).  One 128-bit descriptor and one SGPR per 1-KiB chunk address all SYM_ROWS
+// row streams of the strip; with 64-bit row pointers the 32 pointers and the 32 q_i of a strip together exceed the 102
+// SGPRs of a wave (the round-1 kernel carried 374 SGPR spills).  aux = 2: nt (the matrix is read once).
+__device__ __forceinline__ sym_d2 sym_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const sym_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 2);
+  sym_d2 o;
+  o.x = __hiloint2double((int)w.y, (int)w.x);
+  o.y = __hiloint2double((int)w.w, (int)w.z);
+  return o;
+}
+
+// Columns [c0, c1) of a full strip (c1 - c0 a multiple of 128 * CH), CH 1-KiB chunks per row and trip, RB rows per
+// batch of loads: acc[r] += sum_j K_rj q_j (row part), Z_s[j] = sum_r K_rj q_r (column part, stored where the column
+// is right of the diagonal block).  MASK: the range touches the diagonal block -- lanes left of the strip's first
+// column (lower triangle) contribute nothing, lanes inside the diagonal block contribute to the row part only.
+template <int CH, int RB, bool MASK>
+__device__ __forceinline__ void sym_columns(__amdgpu_buffer_rsrc_t rsrc, const unsigned (&vrow)[SYM_ROWS],
+                                            const double* __restrict__ q, double* __restrict__ Zs, long long i0, int lane,
+                                            long long c0, long long c1, double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS]) {
+#pragma unroll 1
+  for (long long cb = c0; cb < c1; cb += 128 * CH) {
+    double2 q4[CH];
+    double z[CH][2];
+    unsigned soff[CH];
+#pragma unroll
+    for (int u4 = 0; u4 < CH; ++u4) {
+      const long long col = cb + u4 * 128 + lane * 2;
+      q4[u4] = *reinterpret_cast<const double2*>(q + col);
+      if (MASK && col < i0) q4[u4] = make_double2(0.0, 0.0);       // (i0 is even: both columns of a lane agree)
+      z[u4][0] = 0.0; z[u4][1] = 0.0;
+      soff[u4] = (unsigned)((cb + u4 * 128) * 8);
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < SYM_ROWS; r0 += RB) {
+      sym_d2 kv[RB][CH];
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+#pragma unroll
+        for (int u4 = 0; u4 < CH; ++u4) kv[u][u4] = sym_load16(rsrc, vrow[r0 + u], soff[u4]);
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+#pragma unroll
+        for (int u4 = 0; u4 < CH; ++u4) {
+          acc[r0 + u] = fma(kv[u][u4].x, q4[u4].x, fma(kv[u][u4].y, q4[u4].y, acc[r0 + u]));
+          z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
+          z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
+        }
+    }
+#pragma unroll
+    for (int u4 = 0; u4 < CH; ++u4) {
+      const long long col = cb + u4 * 128 + lane * 2;
+      if (!MASK || col >= i0 + SYM_ROWS) *reinterpret_cast<double2*>(Zs + col) = make_double2(z[u4][0], z[u4][1]);
+    }
+  }
+}
+
+// one strip: rows [s SYM_ROWS, (s+1) SYM_ROWS), columns >= s SYM_ROWS; row pitch `ld` doubles (>= N, even)
 // `part` of `nparts` (a power of two, 2 .. SYM_MAX_PARTS): the strip's column range is cut into nparts pieces (at
 // multiples of 128) and each piece is its own work item with its own row partials, so that enough waves stream
 // whatever the share of the triangle a launch covers (one GPU: 2 parts = 4096 waves; 1/8 of the pairs: 16 parts)
-__device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr /* first row of the strip */,
+__device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr /* first row of the strip */, long long ld,
                                                    const double* __restrict__ q, double* __restrict__ yrow,
                                                    double* __restrict__ Z, long long N, long long s, int lane, int part,
                                                    int nparts) {
   const long long i0 = s * SYM_ROWS;
   const int nrows = (int)((N - i0 < SYM_ROWS) ? N - i0 : SYM_ROWS);
-  double qi[SYM_ROWS];
-#pragma unroll
-  for (int r = 0; r < SYM_ROWS; ++r) qi[r] = (r < nrows) ? q[i0 + r] : 0.0;
-  double acc[SYM_ROWS];
-#pragma unroll
-  for (int r = 0; r < SYM_ROWS; ++r) acc[r] = 0.0;
   double* __restrict__ Zs = Z + sym_z_offset(s, N) - (i0 + SYM_ROWS);   // so that Zs[j] is the entry of column j
   const long long cstart = (i0 / 128) * 128;
   const long long cpiece = ((N - cstart) / (128 * nparts)) * 128;
   const long long cbeg = cstart + part * cpiece, cend = (part == nparts - 1) ? N : cbeg + cpiece;
-  // main loop: 512 columns per trip = 4 KiB contiguous per row (8 rows x 4 chunks = 32 loads in flight; with
-  // 1 KiB per row and 32 rows in flight every load of a batch opened a different DRAM page 512 KiB apart)
-  long long c = cbeg + lane * 2;
-  const long long first_full = ((i0 + SYM_ROWS + 127) / 128) * 128;   // from here on every column is off-diagonal
   if (nrows == SYM_ROWS) {
-    // triangle / diagonal chunks first with the general loop below, then the wide loop
+    double qi[SYM_ROWS], acc[SYM_ROWS];
+    unsigned vrow[SYM_ROWS];
+#pragma unroll
+    for (int r = 0; r < SYM_ROWS; ++r) { qi[r] = q[i0 + r]; acc[r] = 0.0; vrow[r] = (unsigned)(r * ld * 8) + (unsigned)lane * 16u; }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Kr), 0, (int)((long long)SYM_ROWS * ld * 8), 0x00020000);
+    // 128-column chunks that touch the diagonal block one at a time with masking, then the bulk 4 KiB per row and trip
+    // (with 1 KiB per row and 32 rows in flight every load of a batch opened a different DRAM page), then the rest
+    const long long first_full = ((i0 + SYM_ROWS + 127) / 128) * 128;   // from here on every column is off-diagonal
     long long cw = cbeg > first_full ? cbeg : first_full;
     if (cw > cend) cw = cend;
     const long long wide_end = cw + ((cend - cw) / (128 * SYM_CH)) * (128 * SYM_CH);
-    // general loop over [cbeg, cw) happens below via `c`; the wide part [cw, wide_end) here
-#pragma unroll 1
-    for (long long cb = cw; cb < wide_end; cb += 128 * SYM_CH) {
-      double2 q4[SYM_CH];
-      double z[SYM_CH][2];
+    sym_columns<1, 8, true>(rsrc, vrow, q, Zs, i0, lane, cbeg, cw, acc, qi);
+    sym_columns<SYM_CH, SYM_RB, false>(rsrc, vrow, q, Zs, i0, lane, cw, wide_end, acc, qi);
+    sym_columns<1, 8, false>(rsrc, vrow, q, Zs, i0, lane, wide_end, cend, acc, qi);
 #pragma unroll
-      for (int u4 = 0; u4 < SYM_CH; ++u4) {
-        q4[u4] = *reinterpret_cast<const double2*>(q + cb + u4 * 128 + lane * 2);
-        z[u4][0] = 0.0; z[u4][1] = 0.0;
-      }
-#pragma unroll
-      for (int r0 = 0; r0 < SYM_ROWS; r0 += SYM_RB) {
-        double2 kv[SYM_RB][SYM_CH];
-#pragma unroll
-        for (int u = 0; u < SYM_RB; ++u)
-#pragma unroll
-          for (int u4 = 0; u4 < SYM_CH; ++u4) {
-            const double* p = Kr + (long long)(r0 + u) * N + cb + u4 * 128 + lane * 2;
-            kv[u][u4].x = __builtin_nontemporal_load(p); kv[u][u4].y = __builtin_nontemporal_load(p + 1);
-          }
-#pragma unroll
-        for (int u = 0; u < SYM_RB; ++u)
-#pragma unroll
-          for (int u4 = 0; u4 < SYM_CH; ++u4) {
-            acc[r0 + u] = fma(kv[u][u4].x, q4[u4].x, fma(kv[u][u4].y, q4[u4].y, acc[r0 + u]));
-            z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
-            z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
-          }
-      }
-#pragma unroll
-      for (int u4 = 0; u4 < SYM_CH; ++u4)
-        *reinterpret_cast<double2*>(Zs + cb + u4 * 128 + lane * 2) = make_double2(z[u4][0], z[u4][1]);
+    for (int r = 0; r < SYM_ROWS; ++r) {
+      const double v = wave_sum(acc[r]);
+      if (lane == 0) yrow[i0 + r] = v;
     }
-    // the general loop covers [cbeg, cw) and then [wide_end, cend)
-#pragma unroll 1
-    for (int part = 0; part < 2; ++part) {
-      const long long pb = part ? wide_end : cbeg, pe = part ? cend : cw;
-      for (long long cc = pb + lane * 2; cc < pe; cc += 128) {
-        const bool in_tri = cc >= i0;
-        const bool off_diag = cc >= i0 + SYM_ROWS;
-        if (!in_tri) continue;
-        const double2 q2 = *reinterpret_cast<const double2*>(q + cc);
-        double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-        for (int r0 = 0; r0 < SYM_ROWS; r0 += 8) {
-          double2 kv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double* p = Kr + (long long)(r0 + u) * N + cc;
-            kv[u].x = __builtin_nontemporal_load(p); kv[u].y = __builtin_nontemporal_load(p + 1);
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            acc[r0 + u] = fma(kv[u].x, q2.x, fma(kv[u].y, q2.y, acc[r0 + u]));
-            z0 = fma(kv[u].x, qi[r0 + u], z0);
-            z1 = fma(kv[u].y, qi[r0 + u], z1);
-          }
-        }
-        if (off_diag) *reinterpret_cast<double2*>(Zs + cc) = make_double2(z0, z1);
-      }
-    }
-    c = cend + lane * 2;   // nothing left for the ragged-strip loop
+    return;
   }
-#pragma unroll 1
-  for (; c < cend; c += 128) {
-    const bool in_tri = c >= i0;                  // i0 and SYM_ROWS are even: both columns of a lane agree
-    const bool off_diag = c >= i0 + SYM_ROWS;
-    if (!in_tri) continue;
-    const double2 q2 = *reinterpret_cast<const double2*>(q + c);
-    double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-    for (int r0 = 0; r0 < SYM_ROWS; r0 += 8) {
-      double2 kv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const double* p = Kr + (long long)(r0 + u) * N + c;
-        if (r0 + u < nrows) { kv[u].x = __builtin_nontemporal_load(p); kv[u].y = __builtin_nontemporal_load(p + 1); }
-        else { kv[u].x = 0.0; kv[u].y = 0.0; }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc[r0 + u] = fma(kv[u].x, q2.x, fma(kv[u].y, q2.y, acc[r0 + u]));
-        z0 = fma(kv[u].x, qi[r0 + u], z0);
-        z1 = fma(kv[u].y, qi[r0 + u], z1);
-      }
+  // ragged strip (only when 2^n < SYM_ROWS: the whole matrix is one partial strip): plain loads, one row at a time
+  for (int r = 0; r < nrows; ++r) {
+    double a = 0.0;
+    for (long long c = cbeg + lane * 2; c < cend; c += 128) {
+      if (c < i0 || c >= N) continue;
+      const double* p = Kr + (long long)r * ld + c;
+      a = fma(p[0], q[c], a);
+      if (c + 1 < N) a = fma(p[1], q[c + 1], a);
     }
-    if (off_diag) *reinterpret_cast<double2*>(Zs + c) = make_double2(z0, z1);
-  }
-#pragma unroll
-  for (int r = 0; r < SYM_ROWS; ++r) {
-    const double v = wave_sum(acc[r]);
-    if (lane == 0 && r < nrows) yrow[i0 + r] = v;
+    a = wave_sum(a);
+    if (lane == 0) yrow[i0 + r] = a;
   }
 }
 
@@ -617,8 +605,11 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr
 // Strip-pair shard (several GPUs): this launch covers the pairs [pair_begin, pair_end); K_lo holds the rows of the
 // strips [pair_begin, pair_end), K_hi those of the mirrored strips [nstrips - pair_end, nstrips - pair_begin).
 // (One GPU: pair range = all pairs, K_lo = K, K_hi = K + (nstrips - npairs) SYM_ROWS N.)
-__global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restrict__ K_lo, const double* __restrict__ K_hi,
-                                                           long long pair_begin, long long pair_end,
+#ifndef BORNVI_SYM_OCC
+#define BORNVI_SYM_OCC 1
+#endif
+__global__ __launch_bounds__(256, BORNVI_SYM_OCC) void quadform_sym_kernel(const double* __restrict__ K_lo, const double* __restrict__ K_hi,
+                                                           long long ld, long long pair_begin, long long pair_end,
                                                            const double* __restrict__ q, double* __restrict__ yrow,
                                                            double* __restrict__ Z, long long N, int nparts_log2) {
   const int lane = threadIdx.x & 63;
@@ -631,9 +622,14 @@ __global__ __launch_bounds__(256) void quadform_sym_kernel(const double* __restr
   const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
   if (w >= pair_end) return;
   double* __restrict__ yh = yrow + part * N;     // row partials of this part (the reduce kernel adds them up)
-  quadform_sym_strip(K_lo + (w - pair_begin) * SYM_ROWS * N, q, yh, Z, N, w, lane, part, nparts);
   const long long s2 = nstrips - 1 - w;
-  if (s2 != w) quadform_sym_strip(K_hi + (s2 - (nstrips - pair_end)) * SYM_ROWS * N, q, yh, Z, N, s2, lane, part, nparts);
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {      // the long strip, then its short mirror (one copy of the code)
+    if (which && s2 == w) break;
+    const long long s = which ? s2 : w;
+    const double* Kr = which ? K_hi + (s2 - (nstrips - pair_end)) * SYM_ROWS * ld : K_lo + (w - pair_begin) * SYM_ROWS * ld;
+    quadform_sym_strip(Kr, ld, q, yh, Z, N, s, lane, part, nparts);
+  }
 }
 
 // y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j]; 64 columns per workgroup, the strips dealt to 4 waves and
@@ -695,8 +691,9 @@ size_t quadform_sym_workspace_doubles(int n) {
 
 // pairs [pair_begin, pair_end) of the N / SYM_ROWS / 2 strip pairs; K_lo / K_hi as in quadform_sym_kernel.
 // ksd2 = sum_j q_j y_j over the (partial) y of this launch.
-hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long pair_begin, long long pair_end,
-                                     const double* q, double* y_or_null, double* ksd2, double* ws, hipStream_t st) {
+hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long ld, long long pair_begin,
+                                     long long pair_end, const double* q, double* y_or_null, double* ksd2, double* ws,
+                                     hipStream_t st) {
   const long long N = 1ll << n;
   const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
   double* yrow = ws;
@@ -711,7 +708,7 @@ hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_
   static const int sym_waves = [] { const char* e = getenv("BORNVI_SYM_WAVES"); int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
   if (npairs > 0) {
     quadform_sym_kernel<<<(unsigned)((nparts * npairs + sym_waves - 1) / sym_waves), 64 * sym_waves, 0, st>>>(
-        K_lo, K_hi, pair_begin, pair_end, q, yrow, Z, N, parts_log2);
+        K_lo, K_hi, ld, pair_begin, pair_end, q, yrow, Z, N, parts_log2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -724,12 +721,12 @@ hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_
   return hipGetLastError();
 }
 
-hipError_t launch_quadform_sym(int n, const double* K, const double* q, double* y_or_null, double* ksd2,
+hipError_t launch_quadform_sym(int n, const double* K, long long ld, const double* q, double* y_or_null, double* ksd2,
                                double* ws, hipStream_t st) {
   const long long N = 1ll << n;
   const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
   const long long npairs = (ns + 1) / 2;
-  return launch_quadform_sym_pairs(n, K, K + (ns - npairs) * SYM_ROWS * N, 0, npairs, q, y_or_null, ksd2, ws, st);
+  return launch_quadform_sym_pairs(n, K, K + (ns - npairs) * SYM_ROWS * ld, ld, 0, npairs, q, y_or_null, ksd2, ws, st);
 }
 
 int quadform_sym_rows_per_strip() { return SYM_ROWS; }

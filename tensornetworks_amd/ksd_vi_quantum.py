@@ -126,7 +126,8 @@ class KSDVariationalInference:
         #   None         = False.  `choose_overlap()` decides between False and "partition" by measurement.
         self.overlap_streams = None
         self.overlap_choice = None
-        self.gram_placement_tries = 3       # dense K_p >= 1 GiB: copies tried for the best-streaming placement (1 = off)
+        self.gram_placement_tries = 1       # (> 1: build that many copies of a dense K_p >= 1 GiB and keep the one the
+                                            # contraction streams fastest -- the round-1 workaround, off by default)
         self.gram_placement = None          # {"contraction_ms_per_try": [...], "kept": index} of the last _prepare_stein
         self._aux_stream = None
 
@@ -186,7 +187,8 @@ class KSDVariationalInference:
                 self._K_pairs = (pa, pb, l1 - l0)
 
                 def build():
-                    K = torch.empty(((l1 - l0) + (h1 - h0), 1 << n), dtype=torch.float64, device=dev)
+                    # (padded row pitch: backend.gram_ld -- the strips' row streams must not share an HBM channel)
+                    K = torch.empty(((l1 - l0) + (h1 - h0), backend.gram_ld(n)), dtype=torch.float64, device=dev)[:, : 1 << n]
                     if l1 > l0:
                         backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(l0, l1), out=K[: l1 - l0])
                         backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(h0, h1), out=K[l1 - l0:])
@@ -199,7 +201,11 @@ class KSDVariationalInference:
                 r0, r1 = self._K_rows
 
                 def build():
-                    return backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
+                    # one GPU, symmetric contraction: padded row pitch (backend.gram_ld); the full-matrix and row-shard
+                    # kernels read contiguous rows
+                    pad = ws == 1 and self.symmetric_contraction
+                    return backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows,
+                                              ld=backend.gram_ld(n) if pad else None)
 
                 def contract(K, q):
                     if ws == 1:
