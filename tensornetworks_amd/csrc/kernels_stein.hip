@@ -480,6 +480,9 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 #ifndef BORNVI_SYM_ROWS
 #define BORNVI_SYM_ROWS 32
 #endif
+#ifndef BORNVI_SYM_ABLATE      // timing-only builds (tools/probes): 1 = no column-partial stores, 2 = no column-part FMAs either
+#define BORNVI_SYM_ABLATE 0
+#endif
 constexpr int SYM_ROWS = BORNVI_SYM_ROWS;
 #ifndef BORNVI_SYM_RB
 #define BORNVI_SYM_RB 8
@@ -508,22 +511,28 @@ __device__ __forceinline__ sym_d2 sym_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
 
 // Columns [c0, c1) of a full strip (c1 - c0 a multiple of 128 * CH), CH 1-KiB chunks per row and trip, RB rows per
 // batch of loads: acc[r] += sum_j K_rj q_j (row part), Z_s[j] = sum_r K_rj q_r (column part, stored where the column
-// is right of the diagonal block).  MASK: the range touches the diagonal block -- lanes left of the strip's first
-// column (lower triangle) contribute nothing, lanes inside the diagonal block contribute to the row part only.
+// is right of the diagonal block).  MASK: the range may touch the diagonal block or end inside a 128-column chunk (2^n
+// < 128) -- lanes left of the strip's first column (lower triangle) or at / beyond c1 contribute nothing (their K
+// loads stay inside the strip's buffer descriptor or are dropped by its range check; q is not read there), lanes
+// inside the diagonal block contribute to the row part only.
 template <int CH, int RB, bool MASK>
-__device__ __forceinline__ void sym_columns(__amdgpu_buffer_rsrc_t rsrc, const unsigned (&vrow)[SYM_ROWS],
+__device__ __forceinline__ void sym_columns(__amdgpu_buffer_rsrc_t rsrc, long long ld,
                                             const double* __restrict__ q, double* __restrict__ Zs, long long i0, int lane,
                                             long long c0, long long c1, double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS]) {
+  const unsigned vlane = (unsigned)lane * 16u;
 #pragma unroll 1
   for (long long cb = c0; cb < c1; cb += 128 * CH) {
+    unsigned ld8 = (unsigned)(ld * 8);
+    asm volatile("" : "+s"(ld8));      // row offsets are formed per trip by the scalar unit (hoisted they spill: 32 x CH values)
     double2 q4[CH];
     double z[CH][2];
     unsigned soff[CH];
 #pragma unroll
     for (int u4 = 0; u4 < CH; ++u4) {
       const long long col = cb + u4 * 128 + lane * 2;
-      q4[u4] = *reinterpret_cast<const double2*>(q + col);
-      if (MASK && col < i0) q4[u4] = make_double2(0.0, 0.0);       // (i0 is even: both columns of a lane agree)
+      if (!MASK) q4[u4] = *reinterpret_cast<const double2*>(q + col);
+      else if (col >= i0 && col + 1 < c1) q4[u4] = *reinterpret_cast<const double2*>(q + col);   // (i0, c1 even unless 2^n = 1)
+      else q4[u4] = make_double2(0.0, 0.0);
       z[u4][0] = 0.0; z[u4][1] = 0.0;
       soff[u4] = (unsigned)((cb + u4 * 128) * 8);
     }
@@ -533,20 +542,92 @@ __device__ __forceinline__ void sym_columns(__amdgpu_buffer_rsrc_t rsrc, const u
 #pragma unroll
       for (int u = 0; u < RB; ++u)
 #pragma unroll
-        for (int u4 = 0; u4 < CH; ++u4) kv[u][u4] = sym_load16(rsrc, vrow[r0 + u], soff[u4]);
+        for (int u4 = 0; u4 < CH; ++u4) kv[u][u4] = sym_load16(rsrc, vlane, soff[u4] + (unsigned)(r0 + u) * ld8);
 #pragma unroll
       for (int u = 0; u < RB; ++u)
 #pragma unroll
         for (int u4 = 0; u4 < CH; ++u4) {
           acc[r0 + u] = fma(kv[u][u4].x, q4[u4].x, fma(kv[u][u4].y, q4[u4].y, acc[r0 + u]));
-          z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
-          z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
+          if (BORNVI_SYM_ABLATE < 2) {
+            z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
+            z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
+          }
         }
     }
 #pragma unroll
     for (int u4 = 0; u4 < CH; ++u4) {
       const long long col = cb + u4 * 128 + lane * 2;
-      if (!MASK || col >= i0 + SYM_ROWS) *reinterpret_cast<double2*>(Zs + col) = make_double2(z[u4][0], z[u4][1]);
+      if (BORNVI_SYM_ABLATE == 0) {
+        if (!MASK || (col >= i0 + SYM_ROWS && col + 1 < c1)) *reinterpret_cast<double2*>(Zs + col) = make_double2(z[u4][0], z[u4][1]);
+      } else if (BORNVI_SYM_ABLATE == 1) {
+        if (z[u4][0] + z[u4][1] == 1.2345e300) Zs[col] = 0.0;     // keeps the FMAs alive, never stores
+      }
+    }
+  }
+}
+
+// The bulk of a strip with a ROLLING window of loads: the 32 rows x 4 chunks of a 512-column trip are 128 load positions;
+// position p is consumed (4 FMAs) and the load of position p + WIN -- of this trip or the next -- is issued into the
+// register pair it frees, so the wave keeps WIN 1-KiB loads in flight at all times.  The batched form above issues a
+// batch, consumes it as it arrives and only then issues the next: its loads in flight fall to zero once per batch (a
+// sawtooth), and with one or two waves per SIMD the chip-wide bytes in flight are then too few to cover the HBM latency:
+// a read-only kernel of the same access shape streams the triangle at 7.0 TB/s, the batched contraction at 6.0.
+// Consecutive positions touch different rows and chunks (no back-to-back dependent FMAs).  Range [c0, c1): multiples of
+// 512 columns right of the diagonal block.  Loads past the last trip carry an offset beyond the descriptor's range:
+// the range check drops them without memory traffic.
+#ifndef BORNVI_SYM_WIN
+#define BORNVI_SYM_WIN 0
+#endif
+
+constexpr int SYM_WIN = BORNVI_SYM_WIN;     // 0: batched loop
+template <int WIN>
+__device__ __forceinline__ void sym_columns_rolling(__amdgpu_buffer_rsrc_t rsrc, long long ld, const double* __restrict__ q,
+                                                    double* __restrict__ Zs, int lane, long long c0, long long c1,
+                                                    double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS]) {
+  static_assert(SYM_ROWS == 32 && WIN >= 8 && WIN <= 64 && 128 % WIN == 0, "window");
+  if (c0 >= c1) return;
+  const unsigned vlane = (unsigned)lane * 16u;
+  unsigned ld8 = (unsigned)(ld * 8);
+  // position -> (row, chunk): groups of 8 rows x 4 chunks; inside a group consecutive positions change row and chunk
+  auto row_of = [](int p) { const int g = p >> 5, i = p & 31; return g * 8 + ((i >> 2) + i) % 8; };
+  auto chunk_of = [](int p) { return p & 3; };
+  sym_d2 kv[WIN];
+  double2 qc[4], qn[4];
+  {
+    const unsigned sb = (unsigned)(c0 * 8);
+#pragma unroll
+    for (int p = 0; p < WIN; ++p) kv[p] = sym_load16(rsrc, vlane, sb + (unsigned)row_of(p) * ld8 + (unsigned)chunk_of(p) * 1024u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qc[c] = *reinterpret_cast<const double2*>(q + c0 + c * 128 + lane * 2);
+  }
+#pragma unroll 1
+  for (long long cb = c0; cb < c1; cb += 512) {
+    const bool has_next = cb + 512 < c1;
+    asm volatile("" : "+s"(ld8));      // the 128 row / chunk offsets are formed per trip by the scalar unit (hoisted they spill)
+    const unsigned sb = (unsigned)(cb * 8);
+    const unsigned sn = has_next ? sb + 4096u : 0xffff0000u;       // beyond num_records: dropped by the range check
+    if (has_next) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) qn[c] = *reinterpret_cast<const double2*>(q + cb + 512 + c * 128 + lane * 2);
+    }
+    double z[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { z[c][0] = 0.0; z[c][1] = 0.0; }
+#pragma unroll
+    for (int p = 0; p < 128; ++p) {
+      const int r = row_of(p), c = chunk_of(p);
+      const sym_d2 v = kv[p % WIN];
+      acc[r] = fma(v.x, qc[c].x, fma(v.y, qc[c].y, acc[r]));
+      z[c][0] = fma(v.x, qi[r], z[c][0]);
+      z[c][1] = fma(v.y, qi[r], z[c][1]);
+      const int np = p + WIN;
+      const int pp = np < 128 ? np : np - 128;
+      kv[p % WIN] = sym_load16(rsrc, vlane, (np < 128 ? sb : sn) + (unsigned)row_of(pp) * ld8 + (unsigned)chunk_of(pp) * 1024u);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<double2*>(Zs + cb + c * 128 + lane * 2) = make_double2(z[c][0], z[c][1]);
+      qc[c] = qn[c];
     }
   }
 }
@@ -567,9 +648,8 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr
   const long long cbeg = cstart + part * cpiece, cend = (part == nparts - 1) ? N : cbeg + cpiece;
   if (nrows == SYM_ROWS) {
     double qi[SYM_ROWS], acc[SYM_ROWS];
-    unsigned vrow[SYM_ROWS];
 #pragma unroll
-    for (int r = 0; r < SYM_ROWS; ++r) { qi[r] = q[i0 + r]; acc[r] = 0.0; vrow[r] = (unsigned)(r * ld * 8) + (unsigned)lane * 16u; }
+    for (int r = 0; r < SYM_ROWS; ++r) { qi[r] = q[i0 + r]; acc[r] = 0.0; }
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Kr), 0, (int)((long long)SYM_ROWS * ld * 8), 0x00020000);
     // 128-column chunks that touch the diagonal block one at a time with masking, then the bulk 4 KiB per row and trip
     // (with 1 KiB per row and 32 rows in flight every load of a batch opened a different DRAM page), then the rest
@@ -577,9 +657,10 @@ __device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr
     long long cw = cbeg > first_full ? cbeg : first_full;
     if (cw > cend) cw = cend;
     const long long wide_end = cw + ((cend - cw) / (128 * SYM_CH)) * (128 * SYM_CH);
-    sym_columns<1, 8, true>(rsrc, vrow, q, Zs, i0, lane, cbeg, cw, acc, qi);
-    sym_columns<SYM_CH, SYM_RB, false>(rsrc, vrow, q, Zs, i0, lane, cw, wide_end, acc, qi);
-    sym_columns<1, 8, false>(rsrc, vrow, q, Zs, i0, lane, wide_end, cend, acc, qi);
+    sym_columns<1, 8, true>(rsrc, ld, q, Zs, i0, lane, cbeg, cw, acc, qi);
+    if (SYM_WIN > 0 && SYM_CH == 4) sym_columns_rolling<(SYM_WIN > 0 ? SYM_WIN : 32)>(rsrc, ld, q, Zs, lane, cw, wide_end, acc, qi);
+    else sym_columns<SYM_CH, SYM_RB, false>(rsrc, ld, q, Zs, i0, lane, cw, wide_end, acc, qi);
+    sym_columns<1, 8, true>(rsrc, ld, q, Zs, i0, lane, wide_end, cend, acc, qi);
 #pragma unroll
     for (int r = 0; r < SYM_ROWS; ++r) {
       const double v = wave_sum(acc[r]);

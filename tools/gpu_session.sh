@@ -16,13 +16,26 @@ run() {   # run <seconds> <logfile> <cmd...>
 }
 mall() { run 120 r2_mall_probe.log tools/_variants/mall_probe; tail -n 25 gpurun_out/r2_mall_probe.log; }
 sym() {
-  for v in 8_4_1 4_4_2 8_2_2 2_8_2 4_4_1 4_2_2; do
-    BORNVI_LIB=$PWD/tools/_variants/libbornvi_sym_$v.so run 240 r2_sym_probe_$v.log python tools/probes/sym_probe.py
-    cat gpurun_out/r2_sym_probe_$v.log | grep -v amdgpu.ids
+  for lib in tools/_variants/libbornvi_sym_*.so; do
+    v=$(basename $lib .so)
+    BORNVI_LIB=$PWD/$lib PADS=${PADS:-0} ALLOCS=${ALLOCS:-4} run 240 r2_sym_probe_$v.log python tools/probes/sym_probe.py
+    grep -v amdgpu.ids gpurun_out/r2_sym_probe_$v.log
   done
 }
 tests() { run 900 r2_gpu_tests.log python -m pytest tests -m gpu -x -q; tail -n 30 gpurun_out/r2_gpu_tests.log; }
 bench() { run 600 r2_bench.log python bench.py --steps 20 --warmup 5; grep '^{' gpurun_out/r2_bench.log > gpurun_out/r2_bench.json; tail -c 3000 gpurun_out/r2_bench.log; }
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
+stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
+           run 300 r2_stream_probe_rand.log tools/_variants/stream_probe 3 0 1; cat gpurun_out/r2_stream_probe_rand.log; }
+alloc() { run 300 r2_alloc_probe.log python tools/probes/alloc_probe.py; grep -v amdgpu.ids gpurun_out/r2_alloc_probe.log; }
+alloc_noz() { BORNVI_SYM_ABLATE=1 run 300 r2_alloc_probe_noz.log python tools/probes/alloc_probe.py; grep -v amdgpu.ids gpurun_out/r2_alloc_probe_noz.log; }
+pmc_tlb() {
+  rm -rf gpurun_out/pmc_tlb
+  run 600 r2_pmc_tlb.log rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE \
+      --kernel-trace -d gpurun_out/pmc_tlb --output-format csv -- python tools/probes/alloc_probe.py
+  grep -v amdgpu.ids gpurun_out/r2_pmc_tlb.log | tail -8
+  python tools/probes/pmc_rows.py 'gpurun_out/pmc_tlb/**/*counter_collection.csv' quadform_sym_kernel > gpurun_out/r2_pmc_tlb_rows.txt; head -80 gpurun_out/r2_pmc_tlb_rows.txt
+}
+counters() { run 120 r2_counters.txt rocprofv3 -L; grep -c . gpurun_out/r2_counters.txt; }
 for step in "$@"; do $step; done
 echo "=== session done"
