@@ -470,37 +470,52 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 // ------------------------------------------------------------------------------------------------
 // symmetric quadratic form: K_p is symmetric (gram_kernel evaluates every entry symmetrically, so it
 // is BITWISE symmetric), hence y = K q needs only the upper triangle: half the HBM traffic.
-// One wave owns a strip of SYM_ROWS rows [i0, i0 + SYM_ROWS) and sweeps the columns j >= i0:
-//   row part   yrow[i] = sum_{j >= i0} K_ij q_j                      (registers, wave-reduced at the end)
-//   column part Z_s[j] = sum_{i in strip} K_ij q_i  for j >= i0 + SYM_ROWS (one 16-byte store per lane
-//               and 128-column chunk; strip s keeps N - (s+1) SYM_ROWS entries)
-// then y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j] in a second kernel.  No atomics: fixed summation order.
-// Traffic: 8 * N^2 / 2 (+ one diagonal block per strip) + 2 * 8 * N^2 / (2 SYM_ROWS) bytes.
+//
+// Work split.  The rows are cut into BANDS of SYM_BAND = 128 rows; a workgroup of four waves owns a band (paired
+// with its mirror band for balance) and one piece of its columns; wave w of the workgroup owns the 32 rows
+// [i0 + 32 w, i0 + 32 w + 32) of the band and sweeps the columns j >= its first row:
+//   row part     yrow[i] = sum_j K_ij q_j over the wave's columns   (32 accumulators per lane, wave-reduced at the end)
+//   column part  z[j]    = sum_{i in the wave's rows} K_ij q_i       (2 per lane and 128-column chunk)
+// The column partials have to leave the wave once per chunk.  Round 1 stored them per 32-row strip (N^2 / 64 doubles
+// = 0.54 GB written and re-read at n = 16, 3 % of the reads) -- and those stores, mixed into the read stream, cost the
+// kernel 8 % (2.85 vs 2.63 ms without them) and made its time depend on where the matrix had been allocated (2.85 ..
+// 3.35 ms: read/write turn-arounds on whichever HBM channels the two buffers share; measured with timing-only builds,
+// tools/probes/sym_probe.py -- neither the row pitch, the TLB reach nor the number of loads in flight mattered).
+// Here the four waves of a band add their column partials through LDS, in fixed order, and ONE 4 KiB store per
+// 512-column trip leaves the workgroup: N^2 / 256 doubles (0.13 GB).  Only the columns next to the diagonal, where
+// the four waves' ranges differ, keep per-wave partials (< 512 doubles per wave).  The second kernel adds, for each
+// column j, the row result and every partial above it: no atomics, fixed summation order, deterministic.
+//
+// Layout facts used below: band S covers rows [128 S, 128 S + 128); its BULK are the columns from
+// bulk_start(S) = min(N, 512 (S / 4 + 1)) on -- right of the diagonal blocks of all four waves and a multiple of the
+// 512-column trip; the NEAR part of wave w are the columns [128-aligned start of its diagonal block, bulk_start).
 // ------------------------------------------------------------------------------------------------
-#ifndef BORNVI_SYM_ROWS
-#define BORNVI_SYM_ROWS 32
-#endif
-#ifndef BORNVI_SYM_ABLATE      // timing-only builds (tools/probes): 1 = no column-partial stores, 2 = no column-part FMAs either
+#ifndef BORNVI_SYM_ABLATE      // timing-only builds (tools/probes): 2 = no column part at all (results invalid)
 #define BORNVI_SYM_ABLATE 0
 #endif
-constexpr int SYM_ROWS = BORNVI_SYM_ROWS;
-#ifndef BORNVI_SYM_RB
-#define BORNVI_SYM_RB 8
-#define BORNVI_SYM_CH 4
-#endif
-constexpr int SYM_RB = BORNVI_SYM_RB, SYM_CH = BORNVI_SYM_CH;   // wide loop: SYM_RB rows x SYM_CH 1-KiB chunks per row in flight
-constexpr int SYM_MAX_PARTS = 16;   // column pieces per strip (row-partial buffers in the workspace)
+constexpr int SYM_ROWS = 32;                        // rows per wave (its row accumulators)
+constexpr int SYM_WAVES = 4;
+constexpr int SYM_BAND = SYM_ROWS * SYM_WAVES;      // rows per workgroup: the unit of the strip-pair shard
+constexpr int SYM_NEAR = 512;                       // per-wave capacity of near-diagonal column partials (< 480 used)
+constexpr int SYM_MAX_PARTS = 16;                   // column pieces per band (row-partial buffers in the workspace)
+constexpr int SYM_MIN_N = 8;                        // smaller matrices (< 256 rows) go through the full-matrix kernel
 typedef double sym_d2 __attribute__((ext_vector_type(2)));
 typedef unsigned int sym_u4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ long long sym_z_offset(long long s, long long N) {
-  return s * N - (long long)SYM_ROWS * (s * (s + 1) / 2);   // Z_s[j - (s+1) SYM_ROWS] lives at this base
+__host__ __device__ inline long long sym_bulk_start(long long S, long long N) {
+  const long long b = 512 * (S / 4 + 1);
+  return b < N ? b : N;
+}
+// offset (doubles) of band S's bulk partials Z2_S[j - bulk_start(S)], j in [bulk_start(S), N): bands in order
+__host__ __device__ inline long long sym_z2_offset(long long S, long long N) {
+  if (N <= 512) return 0;
+  const long long m = S / 4, r = S % 4;
+  return 4 * m * N - 1024 * m * (m + 1) + r * (N - 512 * (m + 1));
 }
 
-// 16 bytes through the strip's buffer descriptor: address = base + voff (per lane: row and lane part, loop-invariant)
-// + soff (wave-uniform: the column position).  One 128-bit descriptor and one SGPR per 1-KiB chunk address all SYM_ROWS
-// row streams of the strip; with 64-bit row pointers the 32 pointers and the 32 q_i of a strip together exceed the 102
-// SGPRs of a wave (the round-1 kernel carried 374 SGPR spills).  aux = 2: nt (the matrix is read once).
+// 16 bytes through the wave's buffer descriptor (its 32 rows): address = base + voff (per lane) + soff (wave-uniform:
+// row and column position, formed by the scalar unit).  With 64-bit row pointers the 32 pointers and the 32 q_i of a
+// wave together exceed its 102 SGPRs (the round-1 kernel carried 374 SGPR spills).  aux = 2: nt (read once).
 __device__ __forceinline__ sym_d2 sym_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const sym_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 2);
   sym_d2 o;
@@ -509,240 +524,161 @@ __device__ __forceinline__ sym_d2 sym_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
   return o;
 }
 
-// Columns [c0, c1) of a full strip (c1 - c0 a multiple of 128 * CH), CH 1-KiB chunks per row and trip, RB rows per
-// batch of loads: acc[r] += sum_j K_rj q_j (row part), Z_s[j] = sum_r K_rj q_r (column part, stored where the column
-// is right of the diagonal block).  MASK: the range may touch the diagonal block or end inside a 128-column chunk (2^n
-// < 128) -- lanes left of the strip's first column (lower triangle) or at / beyond c1 contribute nothing (their K
-// loads stay inside the strip's buffer descriptor or are dropped by its range check; q is not read there), lanes
-// inside the diagonal block contribute to the row part only.
-template <int CH, int RB, bool MASK>
-__device__ __forceinline__ void sym_columns(__amdgpu_buffer_rsrc_t rsrc, long long ld,
-                                            const double* __restrict__ q, double* __restrict__ Zs, long long i0, int lane,
-                                            long long c0, long long c1, double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS]) {
-  const unsigned vlane = (unsigned)lane * 16u;
-#pragma unroll 1
-  for (long long cb = c0; cb < c1; cb += 128 * CH) {
-    unsigned ld8 = (unsigned)(ld * 8);
-    asm volatile("" : "+s"(ld8));      // row offsets are formed per trip by the scalar unit (hoisted they spill: 32 x CH values)
-    double2 q4[CH];
-    double z[CH][2];
-    unsigned soff[CH];
-#pragma unroll
-    for (int u4 = 0; u4 < CH; ++u4) {
-      const long long col = cb + u4 * 128 + lane * 2;
-      if (!MASK) q4[u4] = *reinterpret_cast<const double2*>(q + col);
-      else if (col >= i0 && col + 1 < c1) q4[u4] = *reinterpret_cast<const double2*>(q + col);   // (i0, c1 even unless 2^n = 1)
-      else q4[u4] = make_double2(0.0, 0.0);
-      z[u4][0] = 0.0; z[u4][1] = 0.0;
-      soff[u4] = (unsigned)((cb + u4 * 128) * 8);
-    }
-#pragma unroll
-    for (int r0 = 0; r0 < SYM_ROWS; r0 += RB) {
-      sym_d2 kv[RB][CH];
-#pragma unroll
-      for (int u = 0; u < RB; ++u)
-#pragma unroll
-        for (int u4 = 0; u4 < CH; ++u4) kv[u][u4] = sym_load16(rsrc, vlane, soff[u4] + (unsigned)(r0 + u) * ld8);
-#pragma unroll
-      for (int u = 0; u < RB; ++u)
-#pragma unroll
-        for (int u4 = 0; u4 < CH; ++u4) {
-          acc[r0 + u] = fma(kv[u][u4].x, q4[u4].x, fma(kv[u][u4].y, q4[u4].y, acc[r0 + u]));
-          if (BORNVI_SYM_ABLATE < 2) {
-            z[u4][0] = fma(kv[u][u4].x, qi[r0 + u], z[u4][0]);
-            z[u4][1] = fma(kv[u][u4].y, qi[r0 + u], z[u4][1]);
-          }
-        }
-    }
-#pragma unroll
-    for (int u4 = 0; u4 < CH; ++u4) {
-      const long long col = cb + u4 * 128 + lane * 2;
-      if (BORNVI_SYM_ABLATE == 0) {
-        if (!MASK || (col >= i0 + SYM_ROWS && col + 1 < c1)) *reinterpret_cast<double2*>(Zs + col) = make_double2(z[u4][0], z[u4][1]);
-      } else if (BORNVI_SYM_ABLATE == 1) {
-        if (z[u4][0] + z[u4][1] == 1.2345e300) Zs[col] = 0.0;     // keeps the FMAs alive, never stores
-      }
-    }
-  }
-}
-
-// The bulk of a strip with a ROLLING window of loads: the 32 rows x 4 chunks of a 512-column trip are 128 load positions;
-// position p is consumed (4 FMAs) and the load of position p + WIN -- of this trip or the next -- is issued into the
-// register pair it frees, so the wave keeps WIN 1-KiB loads in flight at all times.  The batched form above issues a
-// batch, consumes it as it arrives and only then issues the next: its loads in flight fall to zero once per batch (a
-// sawtooth), and with one or two waves per SIMD the chip-wide bytes in flight are then too few to cover the HBM latency:
-// a read-only kernel of the same access shape streams the triangle at 7.0 TB/s, the batched contraction at 6.0.
-// Consecutive positions touch different rows and chunks (no back-to-back dependent FMAs).  Range [c0, c1): multiples of
-// 512 columns right of the diagonal block.  Loads past the last trip carry an offset beyond the descriptor's range:
-// the range check drops them without memory traffic.
-#ifndef BORNVI_SYM_WIN
-#define BORNVI_SYM_WIN 0
-#endif
-
-constexpr int SYM_WIN = BORNVI_SYM_WIN;     // 0: batched loop
-template <int WIN>
-__device__ __forceinline__ void sym_columns_rolling(__amdgpu_buffer_rsrc_t rsrc, long long ld, const double* __restrict__ q,
-                                                    double* __restrict__ Zs, int lane, long long c0, long long c1,
-                                                    double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS]) {
-  static_assert(SYM_ROWS == 32 && WIN >= 8 && WIN <= 64 && 128 % WIN == 0, "window");
-  if (c0 >= c1) return;
-  const unsigned vlane = (unsigned)lane * 16u;
+// One trip of a wave over CH 128-column chunks starting at column cb: 32 rows x CH chunks, RB rows per batch of loads.
+// acc[r] += sum_j K_rj q4_j (row part); z[c] = sum_r K_rj q_r (column part of this trip).
+template <int CH, int RB>
+__device__ __forceinline__ void sym_trip(__amdgpu_buffer_rsrc_t rsrc, long long ld, unsigned vlane, long long cb,
+                                         const double2 (&q4)[CH], double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS],
+                                         double (&z)[CH][2]) {
   unsigned ld8 = (unsigned)(ld * 8);
-  // position -> (row, chunk): groups of 8 rows x 4 chunks; inside a group consecutive positions change row and chunk
-  auto row_of = [](int p) { const int g = p >> 5, i = p & 31; return g * 8 + ((i >> 2) + i) % 8; };
-  auto chunk_of = [](int p) { return p & 3; };
-  sym_d2 kv[WIN];
-  double2 qc[4], qn[4];
-  {
-    const unsigned sb = (unsigned)(c0 * 8);
+  asm volatile("" : "+s"(ld8));      // row offsets are formed per trip by the scalar unit (hoisted they spill: 32 x CH values)
+  unsigned soff[CH];
 #pragma unroll
-    for (int p = 0; p < WIN; ++p) kv[p] = sym_load16(rsrc, vlane, sb + (unsigned)row_of(p) * ld8 + (unsigned)chunk_of(p) * 1024u);
+  for (int c = 0; c < CH; ++c) { z[c][0] = 0.0; z[c][1] = 0.0; soff[c] = (unsigned)((cb + c * 128) * 8); }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qc[c] = *reinterpret_cast<const double2*>(q + c0 + c * 128 + lane * 2);
+  for (int r0 = 0; r0 < SYM_ROWS; r0 += RB) {
+    sym_d2 kv[RB][CH];
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) kv[u][c] = sym_load16(rsrc, vlane, soff[c] + (unsigned)(r0 + u) * ld8);
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        acc[r0 + u] = fma(kv[u][c].x, q4[c].x, fma(kv[u][c].y, q4[c].y, acc[r0 + u]));
+        if (BORNVI_SYM_ABLATE < 2) {
+          z[c][0] = fma(kv[u][c].x, qi[r0 + u], z[c][0]);
+          z[c][1] = fma(kv[u][c].y, qi[r0 + u], z[c][1]);
+        }
+      }
   }
-#pragma unroll 1
-  for (long long cb = c0; cb < c1; cb += 512) {
-    const bool has_next = cb + 512 < c1;
-    asm volatile("" : "+s"(ld8));      // the 128 row / chunk offsets are formed per trip by the scalar unit (hoisted they spill)
-    const unsigned sb = (unsigned)(cb * 8);
-    const unsigned sn = has_next ? sb + 4096u : 0xffff0000u;       // beyond num_records: dropped by the range check
-    if (has_next) {
+}
+
+// One band for one workgroup: wave `wave` owns rows [128 S + 32 wave, + 32).  part 0 also sweeps the NEAR columns.
+// All four waves run the same number of bulk trips (one workgroup barrier each).
+__device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb /* first row of the band */, long long ld,
+                                                  const double* __restrict__ q, double* __restrict__ yrow,
+                                                  double* __restrict__ Z1, double* __restrict__ Z2, long long N, long long S,
+                                                  int lane, int wave, int part, int nparts, sym_d2 (*zbuf)[SYM_WAVES][256]) {
+  const long long i0 = S * SYM_BAND + (long long)wave * SYM_ROWS;        // first row of this wave
+  const double* __restrict__ Kr = Kb + (long long)wave * SYM_ROWS * ld;
+  const unsigned vlane = (unsigned)lane * 16u;
+  double qi[SYM_ROWS], acc[SYM_ROWS];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) qn[c] = *reinterpret_cast<const double2*>(q + cb + 512 + c * 128 + lane * 2);
+  for (int r = 0; r < SYM_ROWS; ++r) { qi[r] = q[i0 + r]; acc[r] = 0.0; }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Kr), 0, (int)((long long)SYM_ROWS * ld * 8), 0x00020000);
+  const long long bulk0 = sym_bulk_start(S, N);
+  if (part == 0) {
+    // NEAR columns, one 128-column chunk at a time: lanes left of the wave's first row (lower triangle) contribute
+    // nothing, lanes inside its diagonal block contribute to the row part only; per-wave column partials Z1
+    double* __restrict__ Z1s = Z1 + (S * SYM_WAVES + wave) * SYM_NEAR - (i0 + SYM_ROWS);     // Z1s[j]
+#pragma unroll 1
+    for (long long cb = (i0 / 128) * 128; cb < bulk0; cb += 128) {
+      const long long col = cb + lane * 2;
+      double2 q4[1];
+      q4[0] = (col >= i0) ? *reinterpret_cast<const double2*>(q + col) : make_double2(0.0, 0.0);   // (i0 is even)
+      double z[1][2];
+      sym_trip<1, 8>(rsrc, ld, vlane, cb, q4, acc, qi, z);
+      if (BORNVI_SYM_ABLATE < 2 && col >= i0 + SYM_ROWS) *reinterpret_cast<double2*>(Z1s + col) = make_double2(z[0][0], z[0][1]);
     }
+  }
+  // BULK: trips of 512 columns; the four waves' column partials are added through LDS (fixed order) and stored once
+  const long long ntrips = (N - bulk0) / 512;
+  const long long tp = (ntrips + nparts - 1) / nparts;
+  const long long t0 = (part * tp < ntrips) ? part * tp : ntrips;
+  const long long t1 = (t0 + tp < ntrips) ? t0 + tp : ntrips;
+  double* __restrict__ Z2s = Z2 + sym_z2_offset(S, N) - bulk0;            // Z2s[j]
+#pragma unroll 1
+  for (long long t = t0; t < t1; ++t) {
+    const long long cb = bulk0 + t * 512;
+    double2 q4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = *reinterpret_cast<const double2*>(q + cb + c * 128 + lane * 2);
     double z[4][2];
+    sym_trip<4, 8>(rsrc, ld, vlane, cb, q4, acc, qi, z);
+    if (BORNVI_SYM_ABLATE < 2) {
+      const int buf = (int)((t - t0) & 1);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { z[c][0] = 0.0; z[c][1] = 0.0; }
-#pragma unroll
-    for (int p = 0; p < 128; ++p) {
-      const int r = row_of(p), c = chunk_of(p);
-      const sym_d2 v = kv[p % WIN];
-      acc[r] = fma(v.x, qc[c].x, fma(v.y, qc[c].y, acc[r]));
-      z[c][0] = fma(v.x, qi[r], z[c][0]);
-      z[c][1] = fma(v.y, qi[r], z[c][1]);
-      const int np = p + WIN;
-      const int pp = np < 128 ? np : np - 128;
-      kv[p % WIN] = sym_load16(rsrc, vlane, (np < 128 ? sb : sn) + (unsigned)row_of(pp) * ld8 + (unsigned)chunk_of(pp) * 1024u);
+      for (int c = 0; c < 4; ++c) zbuf[buf][wave][c * 64 + lane] = (sym_d2){z[c][0], z[c][1]};
+      __syncthreads();
+      const int tid = wave * 64 + lane;                 // columns cb + 2 tid, cb + 2 tid + 1
+      const sym_d2 a0 = zbuf[buf][0][tid], a1 = zbuf[buf][1][tid], a2 = zbuf[buf][2][tid], a3 = zbuf[buf][3][tid];
+      const sym_d2 sum = (a0 + a1) + (a2 + a3);
+      *reinterpret_cast<double2*>(Z2s + cb + 2 * tid) = make_double2(sum.x, sum.y);
     }
+  }
+  __syncthreads();      // the LDS buffers are reused by the next band of this workgroup
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<double2*>(Zs + cb + c * 128 + lane * 2) = make_double2(z[c][0], z[c][1]);
-      qc[c] = qn[c];
-    }
+  for (int r = 0; r < SYM_ROWS; ++r) {
+    const double v = wave_sum(acc[r]);
+    if (lane == 0) yrow[i0 + r] = v;
   }
 }
 
-// one strip: rows [s SYM_ROWS, (s+1) SYM_ROWS), columns >= s SYM_ROWS; row pitch `ld` doubles (>= N, even)
-// `part` of `nparts` (a power of two, 2 .. SYM_MAX_PARTS): the strip's column range is cut into nparts pieces (at
-// multiples of 128) and each piece is its own work item with its own row partials, so that enough waves stream
-// whatever the share of the triangle a launch covers (one GPU: 2 parts = 4096 waves; 1/8 of the pairs: 16 parts)
-__device__ __forceinline__ void quadform_sym_strip(const double* __restrict__ Kr /* first row of the strip */, long long ld,
-                                                   const double* __restrict__ q, double* __restrict__ yrow,
-                                                   double* __restrict__ Z, long long N, long long s, int lane, int part,
-                                                   int nparts) {
-  const long long i0 = s * SYM_ROWS;
-  const int nrows = (int)((N - i0 < SYM_ROWS) ? N - i0 : SYM_ROWS);
-  double* __restrict__ Zs = Z + sym_z_offset(s, N) - (i0 + SYM_ROWS);   // so that Zs[j] is the entry of column j
-  const long long cstart = (i0 / 128) * 128;
-  const long long cpiece = ((N - cstart) / (128 * nparts)) * 128;
-  const long long cbeg = cstart + part * cpiece, cend = (part == nparts - 1) ? N : cbeg + cpiece;
-  if (nrows == SYM_ROWS) {
-    double qi[SYM_ROWS], acc[SYM_ROWS];
-#pragma unroll
-    for (int r = 0; r < SYM_ROWS; ++r) { qi[r] = q[i0 + r]; acc[r] = 0.0; }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Kr), 0, (int)((long long)SYM_ROWS * ld * 8), 0x00020000);
-    // 128-column chunks that touch the diagonal block one at a time with masking, then the bulk 4 KiB per row and trip
-    // (with 1 KiB per row and 32 rows in flight every load of a batch opened a different DRAM page), then the rest
-    const long long first_full = ((i0 + SYM_ROWS + 127) / 128) * 128;   // from here on every column is off-diagonal
-    long long cw = cbeg > first_full ? cbeg : first_full;
-    if (cw > cend) cw = cend;
-    const long long wide_end = cw + ((cend - cw) / (128 * SYM_CH)) * (128 * SYM_CH);
-    sym_columns<1, 8, true>(rsrc, ld, q, Zs, i0, lane, cbeg, cw, acc, qi);
-    if (SYM_WIN > 0 && SYM_CH == 4) sym_columns_rolling<(SYM_WIN > 0 ? SYM_WIN : 32)>(rsrc, ld, q, Zs, lane, cw, wide_end, acc, qi);
-    else sym_columns<SYM_CH, SYM_RB, false>(rsrc, ld, q, Zs, i0, lane, cw, wide_end, acc, qi);
-    sym_columns<1, 8, true>(rsrc, ld, q, Zs, i0, lane, wide_end, cend, acc, qi);
-#pragma unroll
-    for (int r = 0; r < SYM_ROWS; ++r) {
-      const double v = wave_sum(acc[r]);
-      if (lane == 0) yrow[i0 + r] = v;
-    }
-    return;
-  }
-  // ragged strip (only when 2^n < SYM_ROWS: the whole matrix is one partial strip): plain loads, one row at a time
-  for (int r = 0; r < nrows; ++r) {
-    double a = 0.0;
-    for (long long c = cbeg + lane * 2; c < cend; c += 128) {
-      if (c < i0 || c >= N) continue;
-      const double* p = Kr + (long long)r * ld + c;
-      a = fma(p[0], q[c], a);
-      if (c + 1 < N) a = fma(p[1], q[c + 1], a);
-    }
-    a = wave_sum(a);
-    if (lane == 0) yrow[i0 + r] = a;
-  }
-}
-
-// wave w owns strips w and nstrips-1-w: a long and a short one, so every wave streams ~N + SYM_ROWS columns.
-// Strip-pair shard (several GPUs): this launch covers the pairs [pair_begin, pair_end); K_lo holds the rows of the
-// strips [pair_begin, pair_end), K_hi those of the mirrored strips [nstrips - pair_end, nstrips - pair_begin).
-// (One GPU: pair range = all pairs, K_lo = K, K_hi = K + (nstrips - npairs) SYM_ROWS N.)
-#ifndef BORNVI_SYM_OCC
-#define BORNVI_SYM_OCC 1
-#endif
-__global__ __launch_bounds__(256, BORNVI_SYM_OCC) void quadform_sym_kernel(const double* __restrict__ K_lo, const double* __restrict__ K_hi,
-                                                           long long ld, long long pair_begin, long long pair_end,
-                                                           const double* __restrict__ q, double* __restrict__ yrow,
-                                                           double* __restrict__ Z, long long N, int nparts_log2) {
+// workgroup = (band pair, column piece): band w and its mirror nbands-1-w -- a long and a short one, so every workgroup
+// streams about the same number of bytes.  Strip-pair shard (several GPUs): this launch covers the pairs
+// [pair_begin, pair_end); K_lo holds the rows of the bands [pair_begin, pair_end), K_hi those of the mirrored bands
+// [nbands - pair_end, nbands - pair_begin).  (One GPU: all pairs, K_lo = K, K_hi = K + (nbands - npairs) SYM_BAND ld.)
+__global__ __launch_bounds__(64 * SYM_WAVES, 2) void quadform_sym_kernel(const double* __restrict__ K_lo, const double* __restrict__ K_hi,
+                                                                       long long ld, long long pair_begin, long long pair_end,
+                                                                       const double* __restrict__ q, double* __restrict__ yrow,
+                                                                       double* __restrict__ Z1, double* __restrict__ Z2,
+                                                                       long long N, int nparts_log2) {
+  __shared__ sym_d2 zbuf[2][SYM_WAVES][256];           // 2 x 4 x 4 KiB: the waves' column partials of a trip
   const int lane = threadIdx.x & 63;
-  // readfirstlane makes the wave index provably uniform, so q_i of the strip and all row addresses live
-  // in scalar registers
-  const long long wi = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long w = pair_begin + (wi >> nparts_log2);
+  // readfirstlane makes the wave index provably uniform, so q_i and all row offsets live in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long w = pair_begin + ((long long)blockIdx.x >> nparts_log2);
   const int nparts = 1 << nparts_log2;
-  const int part = (int)(wi & (nparts - 1));
-  const long long nstrips = (N + SYM_ROWS - 1) / SYM_ROWS;
+  const int part = (int)(blockIdx.x & (unsigned)(nparts - 1));
+  const long long nbands = N / SYM_BAND;
   if (w >= pair_end) return;
-  double* __restrict__ yh = yrow + part * N;     // row partials of this part (the reduce kernel adds them up)
-  const long long s2 = nstrips - 1 - w;
+  double* __restrict__ yh = yrow + part * N;     // row partials of this piece (the reduce kernel adds them up)
+  const long long S2 = nbands - 1 - w;
 #pragma unroll 1
-  for (int which = 0; which < 2; ++which) {      // the long strip, then its short mirror (one copy of the code)
-    if (which && s2 == w) break;
-    const long long s = which ? s2 : w;
-    const double* Kr = which ? K_hi + (s2 - (nstrips - pair_end)) * SYM_ROWS * ld : K_lo + (w - pair_begin) * SYM_ROWS * ld;
-    quadform_sym_strip(Kr, ld, q, yh, Z, N, s, lane, part, nparts);
+  for (int which = 0; which < 2; ++which) {      // the long band, then its short mirror (one copy of the code)
+    if (which && S2 == w) break;
+    const long long S = which ? S2 : w;
+    const double* Kb = which ? K_hi + (S2 - (nbands - pair_end)) * SYM_BAND * ld : K_lo + (w - pair_begin) * SYM_BAND * ld;
+    quadform_sym_band(Kb, ld, q, yh, Z1, Z2, N, S, lane, wave, part, nparts, zbuf);
   }
 }
 
-// y_j = yrow[j] + sum_{s < j / SYM_ROWS} Z_s[j]; 64 columns per workgroup, the strips dealt to 4 waves and
-// combined through LDS in wave order; also the per-workgroup partial of q . y.
-// With a strip-pair shard only the strips [lo0, lo1) and [hi0, hi1) belong to this GPU: the sums run over those
-// (and yrow counts only where column j's own strip is one of them); y is then this GPU's PARTIAL of K q.
-__global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* __restrict__ yrow, const double* __restrict__ Z,
-                                                                  const double* __restrict__ q, double* __restrict__ y,
-                                                                  double* __restrict__ partials, long long N,
-                                                                  long long lo0, long long lo1, long long hi0, long long hi1,
-                                                                  int nparts) {
+// y_j = sum over the pieces of yrow[j] + every column partial above row j: the bulk partials Z2 of the bands
+// S < 4 (j / 512) and the near partials Z1 of the waves s in [16 (j / 512), j / 32).  64 columns per workgroup, the
+// partials dealt to 4 waves and combined through LDS in wave order; also the per-workgroup partial of q . y.
+// With a strip-pair shard only the bands [lo0, lo1) and [hi0, hi1) belong to this GPU: the sums run over those (and
+// yrow counts only where column j's own band is one of them); y is then this GPU's PARTIAL of K q.
+__global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* __restrict__ yrow, const double* __restrict__ Z1,
+                                                                  const double* __restrict__ Z2, const double* __restrict__ q,
+                                                                  double* __restrict__ y, double* __restrict__ partials,
+                                                                  long long N, long long lo0, long long lo1, long long hi0,
+                                                                  long long hi1, int nparts) {
   __shared__ double part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long j = (long long)blockIdx.x * 64 + lane;
   double acc = 0.0;
   if (j < N) {
-    const long long sj = j / SYM_ROWS;              // strips strictly above column j's own strip contribute
+    const long long smax = 4 * (j / 512);           // bands whose bulk starts at or left of column j
 #pragma unroll 1
     for (int rg = 0; rg < 2; ++rg) {
       const long long r0 = rg ? hi0 : lo0;
-      const long long ns = rg ? (hi1 < sj ? hi1 : sj) : (lo1 < sj ? lo1 : sj);
+      const long long ns = rg ? (hi1 < smax ? hi1 : smax) : (lo1 < smax ? lo1 : smax);
       // eight loads in flight per lane (the adds keep their order: the sum is the same as the plain loop's)
-      long long s = r0 + wave;
-      for (; s + 28 < ns; s += 32) {
+      long long S = r0 + wave;
+      for (; S + 28 < ns; S += 32) {
         double zv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) zv[u] = __builtin_nontemporal_load(Z + sym_z_offset(s + 4 * u, N) + (j - (s + 4 * u + 1) * SYM_ROWS));
+        for (int u = 0; u < 8; ++u) zv[u] = __builtin_nontemporal_load(Z2 + sym_z2_offset(S + 4 * u, N) + (j - sym_bulk_start(S + 4 * u, N)));
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += zv[u];
       }
-      for (; s < ns; s += 4)
-        acc += Z[sym_z_offset(s, N) + (j - (s + 1) * SYM_ROWS)];
+      for (; S < ns; S += 4) acc += Z2[sym_z2_offset(S, N) + (j - sym_bulk_start(S, N))];
+    }
+    for (long long s = 16 * (j / 512) + wave; s < j / SYM_ROWS; s += 4) {     // waves whose NEAR range holds column j
+      const long long S = s / SYM_WAVES;
+      if ((S >= lo0 && S < lo1) || (S >= hi0 && S < hi1)) acc += Z1[s * SYM_NEAR + (j - (s + 1) * SYM_ROWS)];
     }
   }
   part[wave][lane] = acc;
@@ -750,8 +686,8 @@ __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* 
   if (wave == 0) {
     double v = 0.0, contrib = 0.0;
     if (j < N) {
-      const long long sj = j / SYM_ROWS;
-      const bool own = (sj >= lo0 && sj < lo1) || (sj >= hi0 && sj < hi1);
+      const long long Sj = j / SYM_BAND;
+      const bool own = (Sj >= lo0 && Sj < lo1) || (Sj >= hi0 && Sj < hi1);
       double yr = 0.0;
       if (own) for (int p = 0; p < nparts; ++p) yr += yrow[(long long)p * N + j];
       v = yr + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
@@ -763,39 +699,43 @@ __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* 
   }
 }
 
+// workspace (doubles): yrow per column piece | per-workgroup partials of q . y | Z1 | Z2
+static long long sym_ws_partials(long long N) { return (((N + 63) / 64) + 31) / 32 * 32; }
 size_t quadform_sym_workspace_doubles(int n) {
   const long long N = 1ll << n;
-  const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
-  const long long z = ns * N - (long long)SYM_ROWS * (ns * (ns + 1) / 2) + 2 * SYM_ROWS;   // all strips (+ slack)
-  return (size_t)(z > 0 ? z : 0) + (size_t)(SYM_MAX_PARTS * N) /*yrow per column piece*/ + (size_t)((N + 63) / 64) /*partials*/ + 64;
+  if (n < SYM_MIN_N) return (size_t)quadform_partials(N) + 64;           // full-matrix kernel
+  const long long nb = N / SYM_BAND;
+  const long long z2 = sym_z2_offset(nb, N);
+  return (size_t)(SYM_MAX_PARTS * N) + (size_t)sym_ws_partials(N) + (size_t)(nb * SYM_WAVES * SYM_NEAR) + (size_t)(z2 > 0 ? z2 : 0) + 64;
 }
 
-// pairs [pair_begin, pair_end) of the N / SYM_ROWS / 2 strip pairs; K_lo / K_hi as in quadform_sym_kernel.
+// pairs [pair_begin, pair_end) of the N / SYM_BAND / 2 band pairs; K_lo / K_hi as in quadform_sym_kernel.
 // ksd2 = sum_j q_j y_j over the (partial) y of this launch.
 hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_hi, long long ld, long long pair_begin,
                                      long long pair_end, const double* q, double* y_or_null, double* ksd2, double* ws,
                                      hipStream_t st) {
+  if (n < SYM_MIN_N) return hipErrorInvalidValue;
   const long long N = 1ll << n;
-  const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
+  const long long nb = N / SYM_BAND;
   double* yrow = ws;
   double* partials = ws + SYM_MAX_PARTS * N;
   const long long nred = (N + 63) / 64;
-  double* Z = partials + ((nred + 31) / 32) * 32;          // keep Z 16-byte aligned (N, offsets are even)
+  double* Z1 = partials + sym_ws_partials(N);               // (16-byte aligned: every offset is even)
+  double* Z2 = Z1 + nb * SYM_WAVES * SYM_NEAR;
   const long long npairs = pair_end - pair_begin;
-  int parts_log2 = 1;                                       // enough column pieces for >= 4096 streaming waves
-  while ((1 << parts_log2) < SYM_MAX_PARTS && (npairs << parts_log2) < 4096) ++parts_log2;
+  int parts_log2 = 0;                                       // enough column pieces for two workgroups per CU
+  static const int min_wgs = [] { const char* e = getenv("BORNVI_SYM_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  while ((1 << parts_log2) < SYM_MAX_PARTS && (npairs << parts_log2) < min_wgs) ++parts_log2;
   const int nparts = 1 << parts_log2;
-  // (waves are independent: BORNVI_SYM_WAVES picks the workgroup size for co-residency experiments)
-  static const int sym_waves = [] { const char* e = getenv("BORNVI_SYM_WAVES"); int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
   if (npairs > 0) {
-    quadform_sym_kernel<<<(unsigned)((nparts * npairs + sym_waves - 1) / sym_waves), 64 * sym_waves, 0, st>>>(
-        K_lo, K_hi, ld, pair_begin, pair_end, q, yrow, Z, N, parts_log2);
+    quadform_sym_kernel<<<(unsigned)(npairs << parts_log2), 64 * SYM_WAVES, 0, st>>>(K_lo, K_hi, ld, pair_begin, pair_end, q, yrow,
+                                                                                  Z1, Z2, N, parts_log2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  long long hi0 = ns - pair_end, hi1 = ns - pair_begin;
-  if (hi0 < pair_end) hi0 = pair_end;                       // odd strip count: the middle strip is its own mirror
-  quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z, q, y_or_null, partials, N, pair_begin, pair_end, hi0, hi1, nparts);
+  long long hi0 = nb - pair_end, hi1 = nb - pair_begin;
+  if (hi0 < pair_end) hi0 = pair_end;                       // odd band count: the middle band is its own mirror
+  quadform_sym_reduce_kernel<<<(unsigned)nred, 256, 0, st>>>(yrow, Z1, Z2, q, y_or_null, partials, N, pair_begin, pair_end, hi0, hi1, nparts);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   sum_partials_kernel<<<1, 256, 0, st>>>(partials, nred, ksd2);
@@ -805,12 +745,16 @@ hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_
 hipError_t launch_quadform_sym(int n, const double* K, long long ld, const double* q, double* y_or_null, double* ksd2,
                                double* ws, hipStream_t st) {
   const long long N = 1ll << n;
-  const long long ns = (N + SYM_ROWS - 1) / SYM_ROWS;
-  const long long npairs = (ns + 1) / 2;
-  return launch_quadform_sym_pairs(n, K, K + (ns - npairs) * SYM_ROWS * ld, ld, 0, npairs, q, y_or_null, ksd2, ws, st);
+  if (n < SYM_MIN_N) {                   // a few KiB: the full-matrix kernel (same result for a symmetric K)
+    if (ld != N) return hipErrorInvalidValue;
+    return launch_quadform(n, K, 0, N, q, y_or_null, ksd2, ws, st);
+  }
+  const long long nb = N / SYM_BAND;
+  const long long npairs = (nb + 1) / 2;
+  return launch_quadform_sym_pairs(n, K, K + (nb - npairs) * SYM_BAND * ld, ld, 0, npairs, q, y_or_null, ksd2, ws, st);
 }
 
-int quadform_sym_rows_per_strip() { return SYM_ROWS; }
+int quadform_sym_rows_per_strip() { return SYM_BAND; }
 
 // ------------------------------------------------------------------------------------------------
 // matrix-free y = K_p q.  The n+1 real vectors v_0 = q, v_{b+1} = s_b o q

@@ -103,7 +103,7 @@ def test_quadform_and_kron_match_oracle(be, dev, n, seed):
     np.testing.assert_array_equal(k_only.cpu().numpy(), ksd2.cpu().numpy())
 
 
-@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 8, 10, 12])
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_symmetric_quadform_equals_full(be, dev, n):
     """Upper-triangle contraction == full-matrix contraction (K_p is bitwise symmetric)."""
     bn, lat, obs, x = synthetic_network(n, 1)
@@ -119,9 +119,18 @@ def test_symmetric_quadform_equals_full(be, dev, n):
     assert abs(k_full.item() - k_sym.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
     # the reference value: dense NumPy product
     np.testing.assert_allclose(y_sym.cpu().numpy(), K.cpu().numpy() @ q.cpu().numpy(), rtol=0, atol=1e-13 * scale)
+    if n >= 8:
+        # a padded row pitch (the [:, :2^n] view of a [2^n, 2^n + 32] buffer) holds the same matrix and contracts to the
+        # same bits; deterministic from call to call
+        Kp = be.stein_gram(S, n, 1.0, ld=2 ** n + 32)
+        assert Kp.stride(0) == 2 ** n + 32 and torch.equal(Kp, K)
+        k_pad, y_pad = be.stein_quadform_sym(Kp, q, n)
+        assert torch.equal(y_pad, y_sym) and torch.equal(k_pad, k_sym)
+        k_again, y_again = be.stein_quadform_sym(K, q, n)
+        assert torch.equal(y_again, y_sym) and torch.equal(k_again, k_sym)
 
 
-@pytest.mark.parametrize("n,world", [(6, 1), (7, 2), (8, 2), (10, 3), (12, 8), (13, 4)])
+@pytest.mark.parametrize("n,world", [(8, 1), (9, 2), (10, 2), (10, 3), (12, 8), (13, 4), (14, 8)])
 def test_sym_strip_pair_shard_sums_to_full(be, dev, n, world):
     """Several GPUs: each rank holds two row blocks of K_p (its strip pairs of the upper triangle) and computes
     an additive share of (K q, q^T K q); the shares (what the all-reduce sums) add up to the full contraction."""
@@ -148,7 +157,7 @@ def test_sym_strip_pair_shard_sums_to_full(be, dev, n, world):
     scale = (K.abs() @ q).max().item()
     assert (total[:-1] - y_ref).abs().max().item() <= 1e-13 * scale
     assert abs(total[-1].item() - k_ref.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
-    assert be.sym_pair_shard(5, 0, 2) is None       # 32 outcomes: one strip, no pairs to deal out
+    assert be.sym_pair_shard(7, 0, 2) is None       # 128 outcomes: one band of 128 rows, no pairs to deal out
 
 
 def test_length_scale(be, dev):

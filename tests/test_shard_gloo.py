@@ -103,7 +103,7 @@ def _sym_worker(rank, world_size, port, n, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size,n", [(2, 7), (3, 8)])
+@pytest.mark.parametrize("world_size,n", [(2, 9), (3, 10)])
 def test_strip_pair_shard_all_reduce(tmp_path, world_size, n):
     """The strip pairs dealt to the ranks cover the upper triangle exactly once: the all-reduced shares are K q and
     q^T K q, bit-identical on every rank (the partition and the collective of the multi-GPU contraction)."""

@@ -22,12 +22,14 @@ sym() {
     grep -v amdgpu.ids gpurun_out/r2_sym_probe_$v.log
   done
 }
+tests_stein() { run 600 r2_gpu_tests_stein.log python -m pytest tests/test_gpu_stein.py tests/test_gpu_shard.py tests/test_gpu_trainer.py -m gpu -x -q; tail -n 15 gpurun_out/r2_gpu_tests_stein.log; }
 tests() { run 900 r2_gpu_tests.log python -m pytest tests -m gpu -x -q; tail -n 30 gpurun_out/r2_gpu_tests.log; }
 bench() { run 600 r2_bench.log python bench.py --steps 20 --warmup 5; grep '^{' gpurun_out/r2_bench.log > gpurun_out/r2_bench.json; tail -c 3000 gpurun_out/r2_bench.log; }
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
            run 300 r2_stream_probe_rand.log tools/_variants/stream_probe 3 0 1; cat gpurun_out/r2_stream_probe_rand.log; }
 alloc() { run 300 r2_alloc_probe.log python tools/probes/alloc_probe.py; grep -v amdgpu.ids gpurun_out/r2_alloc_probe.log; }
+alloc_parts() { for w in 512 1024 2048; do BORNVI_SYM_MIN_WGS=$w ALLOCS=4 run 300 r2_alloc_probe_wgs$w.log python tools/probes/alloc_probe.py; echo "min_wgs $w"; grep "^alloc" gpurun_out/r2_alloc_probe_wgs$w.log | cut -c1-60; done; }
 alloc_noz() { BORNVI_SYM_ABLATE=1 run 300 r2_alloc_probe_noz.log python tools/probes/alloc_probe.py; grep -v amdgpu.ids gpurun_out/r2_alloc_probe_noz.log; }
 pmc_tlb() {
   rm -rf gpurun_out/pmc_tlb
