@@ -62,6 +62,7 @@ struct bornvi_ctx {
   int prefix_share = 0;     // OPT-IN: in a parameter-shift batch a shifted circuit starts from the base
                             // circuit's state before the first pass its parameter touches -- bit-identical rows, ~40 % fewer
                             // circuit-passes.  Off by default: the north-star path is 2P full circuit evaluations.
+  int batched_quadform = 1; // bornvi_stein_quadform with B > 1: 1 = one MFMA pass over K, 0 = B GEMV passes (A/B switch)
   int direct_stages = 3;    // fast kernel: bit 0 / 1 = first / last stage of a pass straight from / to HBM where the plan allows
                             // (A/B switch; bits 2.. = 1 + the only pass allowed to, for debugging)
 };
@@ -347,6 +348,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   if (!std::strcmp(name, "fast_path")) { h->fast_path = value ? 1 : 0; return BORNVI_OK; }
   if (!std::strcmp(name, "circuit_cus")) { h->circuit_cus = (int)value; return BORNVI_OK; }
   if (!std::strcmp(name, "prefix_share")) { h->prefix_share = (int)value; return BORNVI_OK; }
+  if (!std::strcmp(name, "batched_quadform")) { h->batched_quadform = value ? 1 : 0; return BORNVI_OK; }
   if (!std::strcmp(name, "direct_stages")) { h->direct_stages = (int)value; return BORNVI_OK; }   // bits 2..: 1 + the only pass allowed (debug)
   if (!std::strcmp(name, "fast_workgroups_per_cu")) {
     if (value < 0 || value > 16) return fail(h, BORNVI_ERR_INVALID, "option value out of range");
@@ -545,9 +547,12 @@ int bornvi_stein_kp_pairs(bornvi_handle h, int n, double length_scale, long long
 }
 
 size_t bornvi_stein_quadform_workspace_bytes(bornvi_handle h, int n, int B) {
-  (void)h; (void)B;
+  (void)h;
   if (n < 1 || n > 30) return 0;
-  return align_up(quadform_partials(1ll << n) * sizeof(double), 256);
+  size_t b = align_up(quadform_partials(1ll << n) * sizeof(double), 256);
+  // the batched (matrix-core) form computes ksd2 from Y: room for Y when the caller does not ask for it
+  if (B > 1 && quadform_batched_supported(n, B)) b += align_up((size_t)B * ((size_t)8 << n), 256);
+  return b;
 }
 
 int bornvi_stein_quadform_rows(bornvi_handle h, int n, const double* K_rows, long long row_begin, long long row_end,
@@ -573,6 +578,12 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
   DEVICE_SCOPE(h);
   const long long N = 1ll << n;
+  if (quadform_batched_supported(n, B) && h->batched_quadform) {
+    // one pass over K on the matrix cores (kernels_batched.hip) instead of B passes of the HBM-bound GEMV
+    double* Yw = Y ? Y : (double*)((char*)workspace + align_up(quadform_partials(N) * sizeof(double), 256));
+    HIPCHK(h, launch_quadform_batched(n, K, Q, B, Yw, ksd2, (hipStream_t)stream));
+    return BORNVI_OK;
+  }
   for (int b = 0; b < B; ++b)
     HIPCHK(h, launch_quadform(n, K, 0, N, Q + b * N, Y ? Y + b * N : nullptr, ksd2 + b, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;

@@ -275,3 +275,33 @@ def test_wrappers_refuse_wrong_sizes(dev):
             pytest.fail(f"call {i} was executed")
     ksd2, y = backend.stein_quadform_sym(K, q, n)             # the well-formed calls still run
     assert y.shape == (N,) and ksd2.shape == (1,)
+
+
+@pytest.mark.parametrize("n,B", [(8, 2), (8, 129), (10, 5), (11, 577), (12, 130)])
+def test_batched_quadform_on_matrix_cores(be, dev, n, B):
+    """bornvi_stein_quadform with B > 1: one pass over K_p with v_mfma_f64_16x16x4 (kernels_batched.hip) against the
+    looped HBM-bound GEMV (option batched_quadform = 0) and a dense fp64 product: Y to 1e-13 * sum |terms|, ksd2 likewise;
+    vector counts that are not multiples of the 128-vector block; Y optional (reference accumulation
+    ksd_vi_quantum.py:123-145, evaluated for B distributions at once)."""
+    bn, lat, obs, x = synthetic_network(n, 4)
+    S, _ = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    K = be.stein_gram(S, n, 1.0)
+    g = torch.Generator().manual_seed(100 * n + B)
+    Q = torch.rand((B, 2 ** n), generator=g, dtype=torch.float64).to(dev)
+    Q /= Q.sum(dim=1, keepdim=True)
+    try:
+        be.set_engine_option(dev, "batched_quadform", 0)
+        k_loop, Y_loop = be.stein_quadform(K, Q, n)
+        be.set_engine_option(dev, "batched_quadform", 1)
+        k_mfma, Y_mfma = be.stein_quadform(K, Q, n)
+        k_only, none = be.stein_quadform(K, Q, n, want_y=False)
+    finally:
+        be.set_engine_option(dev, "batched_quadform", 1)
+    terms = (K.abs() @ Q.t()).t()                       # sum_j |K_ij| q_bj
+    assert ((Y_mfma - Y_loop).abs() <= 1e-13 * terms).all()
+    assert ((Y_mfma - (K @ Q.t()).t()).abs() <= 1e-13 * terms).all()
+    scale = (Q * terms).sum(dim=1)
+    assert ((k_mfma - k_loop).abs() <= 1e-13 * scale).all()
+    assert none is None and torch.equal(k_only, k_mfma)
+    k_again, Y_again = be.stein_quadform(K, Q, n)       # deterministic
+    assert torch.equal(Y_again, Y_mfma) and torch.equal(k_again, k_mfma)

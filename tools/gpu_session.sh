@@ -29,6 +29,7 @@ smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
            run 300 r2_stream_probe_rand.log tools/_variants/stream_probe 3 0 1; cat gpurun_out/r2_stream_probe_rand.log; }
 alloc() { run 300 r2_alloc_probe.log python tools/probes/alloc_probe.py; grep -v amdgpu.ids gpurun_out/r2_alloc_probe.log; }
+batched() { run 600 r2_batched_probe.log python tools/probes/batched_probe.py; grep -v amdgpu.ids gpurun_out/r2_batched_probe.log | tail -6; }
 alloc_parts() { for w in 512 1024 2048; do BORNVI_SYM_MIN_WGS=$w ALLOCS=4 run 300 r2_alloc_probe_wgs$w.log python tools/probes/alloc_probe.py; echo "min_wgs $w"; grep "^alloc" gpurun_out/r2_alloc_probe_wgs$w.log | cut -c1-60; done; }
 alloc_noz() { BORNVI_SYM_ABLATE=1 run 300 r2_alloc_probe_noz.log python tools/probes/alloc_probe.py; grep -v amdgpu.ids gpurun_out/r2_alloc_probe_noz.log; }
 pmc_tlb() {
