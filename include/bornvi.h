@@ -72,7 +72,10 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
  * several tiles; default 0 = chosen per plan: 11 up to n = 16, above that 13 where it saves an eighth of the passes), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
  * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
  * results are INVALID while non-zero).  Engine switches (no effect on results): "fast_path",
- * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus"; "prefix_share" (default 0; 1: in
+ * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus", "batched_quadform" (0: bornvi_stein_quadform
+ * with B > 1 runs B GEMV passes instead of one matrix-core pass); "grad_engine" (default 0 = the reference's
+ * parameter-shift rule; 1 = OPT-IN: bornvi_paramshift_grad answers with adjoint differentiation, see below);
+ * "prefix_share" (default 0; 1: in
  * bornvi_paramshift_probs* a shifted circuit starts from the base circuit's state at the first pass
  * its parameter touches instead of |0..0> -- the rows are bit-identical, fewer passes are run). */
 int bornvi_set_option(bornvi_handle h, const char* name, long long value);
@@ -251,6 +254,22 @@ int bornvi_clip_cast_grad(bornvi_handle h, int P, const double* grad64, double m
 int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, double max_norm,
                                 const double* loss, float* grad32, float* total_norm,
                                 float* found_inf, bornvi_stream stream);
+
+/* ---- adjoint differentiation: OPT-IN second gradient engine ---------------------------
+ * The reference differentiates with diff_method="parameter-shift" (quantum_born_machine.py:58, :90, :114): 2P circuit
+ * evaluations.  For L = f(q) the same gradient is  dL/dtheta_k = Im <lambda_k| P_k |phi_k>  (one forward and one
+ * backward walk over the gates with two states, about three circuit evaluations).  Equal to the parameter-shift
+ * gradient to rounding; never used unless the caller asks (it changes what "2P evaluations" means).
+ *   bornvi_adjoint_state: theta dev [P] -> state dev [2^n] complex128 = U(theta)|0..0> (canonical order, wire 0 = MSB),
+ *                         probs dev [2^n] = |state|^2 or NULL;
+ *   bornvi_adjoint_vjp:   state (as returned above, left untouched), dLdq dev [2^n] -> grad dev [P]
+ *                         = d/dtheta sum_z dLdq[z] q_z(theta).  Deterministic (fixed summation order). */
+size_t bornvi_adjoint_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers);
+int bornvi_adjoint_state(bornvi_handle h, int ansatz, int n, int layers, const double* theta, double* state,
+                         double* probs, void* workspace, size_t workspace_bytes, bornvi_stream stream);
+int bornvi_adjoint_vjp(bornvi_handle h, int ansatz, int n, int layers, const double* theta, const double* state,
+                       const double* dLdq, double* grad, void* workspace, size_t workspace_bytes,
+                       bornvi_stream stream);
 
 /* ---- introspection (host only, no GPU needed): serialised execution plan of a circuit ------
  * (passes / stages / fused gates) as uint32 words; used by the CPU tests to check the

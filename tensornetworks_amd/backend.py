@@ -206,6 +206,39 @@ def paramshift_grad(ansatz_type, n, layers, theta, dLdq, p_begin, p_end, p_strid
     return grad
 
 
+def adjoint_state(ansatz_type, n, layers, theta, want_probs=True):
+    """OPT-IN adjoint engine, forward walk: theta float64 [P] -> (state complex128 [2^n], probs float64 [2^n] or None)."""
+    dev = theta.device
+    h = _ext.handle_for(dev)
+    aid = ansatz_id(ansatz_type)
+    _chk_n(n)
+    _chk(theta, torch.float64, dev, "theta", num_params(ansatz_type, n, layers))
+    state = torch.empty(1 << n, dtype=torch.complex128, device=dev)
+    probs = torch.empty(1 << n, dtype=torch.float64, device=dev) if want_probs else None
+    ws = _ws(dev, _cached_size(h, "bornvi_adjoint_workspace_bytes", aid, n, layers), "adjoint")
+    h.call("bornvi_adjoint_state", aid, n, layers, _ptr(theta), _ptr(state), _ptr(probs) if want_probs else None, _ptr(ws),
+           ws.numel(), _ext.stream_ptr(dev))
+    return state, probs
+
+
+def adjoint_vjp(ansatz_type, n, layers, theta, state, dLdq):
+    """OPT-IN adjoint engine, backward walk: grad[p] = d/dtheta_p sum_z dLdq[z] q_z(theta), float64 [P] -- the quantity
+    paramshift_grad computes with 2P circuits, from one forward state and one backward walk."""
+    dev = theta.device
+    h = _ext.handle_for(dev)
+    aid = ansatz_id(ansatz_type)
+    _chk_n(n)
+    P = num_params(ansatz_type, n, layers)
+    _chk(theta, torch.float64, dev, "theta", P)
+    _chk(state, torch.complex128, dev, "state", 1 << n)
+    _chk(dLdq, torch.float64, dev, "dLdq", 1 << n)
+    grad = torch.zeros(P, dtype=torch.float64, device=dev)
+    ws = _ws(dev, _cached_size(h, "bornvi_adjoint_workspace_bytes", aid, n, layers), "adjoint")
+    h.call("bornvi_adjoint_vjp", aid, n, layers, _ptr(theta), _ptr(state), _ptr(dLdq), _ptr(grad), _ptr(ws), ws.numel(),
+           _ext.stream_ptr(dev))
+    return grad
+
+
 def gate1q_apply(state, n, wire, U):
     """In-place one-qubit gate on state complex128 [B, 2^n] (one HBM round trip)."""
     dev = state.device

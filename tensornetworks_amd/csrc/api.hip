@@ -41,6 +41,17 @@ struct DevPlan {
 };
 
 
+// Block sequence of the adjoint walk (kernels_adjoint.hip) for one (ansatz, n, layers): rotation blocks and entangler
+// blocks in program order; built on the host from the same gate list as the plans.
+struct AdjPlan {
+  struct Step { int is_rot; int index; };        // index into rots / ents
+  std::vector<Step> steps;
+  std::vector<AdjRotBlock> rots;
+  std::vector<AdjEntangler> ents_fwd, ents_bwd;  // psi'[y] = s(y) psi[A y]  /  psi[x] = s(y) psi'[y], y = A^-1 x
+  int* d_slot_param = nullptr;                   // [4 * rots.size()] parameter of (rotation block, element) or -1
+  int n_params = 0;
+};
+
 thread_local std::string g_create_error;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -52,6 +63,7 @@ struct bornvi_ctx {
   std::string err;
   PlanOptions opt;
   std::map<std::tuple<int, int, int>, std::unique_ptr<DevPlan>> plans;  // (ansatz | -1 = kron, n, layers)
+  std::map<std::tuple<int, int, int>, std::unique_ptr<AdjPlan>> adj_plans;
   size_t max_lds_prepared = 0;
   int debug_flags = 0;  // timing-only ablations of circuit_pass_kernel (results are WRONG when non-zero)
   int num_cus = 256;    // multiProcessorCount
@@ -62,6 +74,8 @@ struct bornvi_ctx {
   int prefix_share = 0;     // OPT-IN: in a parameter-shift batch a shifted circuit starts from the base
                             // circuit's state before the first pass its parameter touches -- bit-identical rows, ~40 % fewer
                             // circuit-passes.  Off by default: the north-star path is 2P full circuit evaluations.
+  int grad_engine = 0;      // OPT-IN: 1 = bornvi_paramshift_grad answers with adjoint differentiation (one
+                            // forward + one backward walk) instead of 2P shifted circuits; same gradient to rounding
   int batched_quadform = 1; // bornvi_stein_quadform with B > 1: 1 = one MFMA pass over K, 0 = B GEMV passes (A/B switch)
   int direct_stages = 3;    // fast kernel: bit 0 / 1 = first / last stage of a pass straight from / to HBM where the plan allows
                             // (A/B switch; bits 2.. = 1 + the only pass allowed to, for debugging)
@@ -297,6 +311,86 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   return BORNVI_OK;
 }
 
+// ---- adjoint walk: gate list -> rotation / entangler blocks ------------------------------------------------------
+bool build_adj_plan(int ansatz, int n, int layers, AdjPlan& out, std::string& msg) {
+  std::vector<Gate> gates;
+  if (!build_gate_list(ansatz, n, layers, gates)) { msg = "unknown ansatz"; return false; }
+  if (n < 1 || n > 30) { msg = "adjoint engine supports 1 <= n <= 30"; return false; }
+  out.n_params = num_params(ansatz, n, layers);
+  std::vector<std::vector<Gate>> per_wire((size_t)n);     // one-qubit gates of the current segment, per wire (they commute across wires)
+  std::vector<Gate> two;                                   // two-qubit gates of the current entangler
+  auto flush_rots = [&]() {
+    for (int w = 0; w < n; ++w) {
+      auto& g = per_wire[(size_t)w];
+      for (size_t i = 0; i < g.size(); i += 4) {
+        AdjRotBlock b{};
+        b.wire = w;
+        b.nrot = (int)std::min<size_t>(4, g.size() - i);
+        for (int e = 0; e < 4; ++e) { b.kind[e] = e < b.nrot ? g[i + e].kind : G_H; b.param[e] = e < b.nrot ? g[i + e].param : -1; }
+        out.steps.push_back({1, (int)out.rots.size()});
+        out.rots.push_back(b);
+      }
+      g.clear();
+    }
+  };
+  auto flush_ent = [&]() -> bool {
+    if (two.empty()) return true;
+    AdjEntangler F{}, Bk{};
+    unsigned L[32], Inv[32];
+    for (int b = 0; b < 32; ++b) { L[b] = b < n ? 1u << b : 0u; Inv[b] = L[b]; }
+    int ncz = 0;
+    for (int k = (int)two.size() - 1; k >= 0; --k) {       // L = C_{k+1} ... C_m while gate k is looked at
+      const int a = n - 1 - two[(size_t)k].w0, b = n - 1 - two[(size_t)k].w1;   // physical bits (wire 0 = MSB)
+      if (two[(size_t)k].kind == G_CZ) {
+        if (ncz >= ADJ_MAX_CZ) return false;
+        F.za[ncz] = L[a]; F.zb[ncz] = L[b]; ++ncz;
+      } else {
+        L[b] ^= L[a];                                       // CNOT(control a, target b): x_b = y_b ^ y_a
+      }
+    }
+    for (size_t k = 0; k < two.size(); ++k)
+      if (two[k].kind == G_CNOT) { const int a = n - 1 - two[k].w0, b = n - 1 - two[k].w1; Inv[b] ^= Inv[a]; }
+    for (int b = 0; b < 32; ++b) { F.row[b] = L[b]; Bk.row[b] = Inv[b]; }
+    F.ncz = ncz; Bk.ncz = ncz;
+    for (int k = 0; k < ncz; ++k) { Bk.za[k] = F.za[k]; Bk.zb[k] = F.zb[k]; }
+    out.steps.push_back({0, (int)out.ents_fwd.size()});
+    out.ents_fwd.push_back(F);
+    out.ents_bwd.push_back(Bk);
+    two.clear();
+    return true;
+  };
+  for (const Gate& g : gates) {
+    if (g.w1 < 0) {
+      if (!two.empty() && !flush_ent()) { msg = "too many CZ gates in one entangler block"; return false; }
+      per_wire[(size_t)g.w0].push_back(g);
+    } else {
+      flush_rots();
+      two.push_back(g);
+    }
+  }
+  flush_rots();
+  if (!flush_ent()) { msg = "too many CZ gates in one entangler block"; return false; }
+  return true;
+}
+
+int get_adj_plan(bornvi_handle h, int ansatz, int n, int layers, AdjPlan** out) {
+  auto key = std::make_tuple(ansatz, n, layers);
+  auto it = h->adj_plans.find(key);
+  if (it != h->adj_plans.end()) { *out = it->second.get(); return BORNVI_OK; }
+  auto ap = std::make_unique<AdjPlan>();
+  std::string msg;
+  if (!build_adj_plan(ansatz, n, layers, *ap, msg)) return fail(h, BORNVI_ERR_UNSUPPORTED, msg);
+  std::vector<int> slots(4 * ap->rots.size() + 4, -1);
+  for (size_t b = 0; b < ap->rots.size(); ++b)
+    for (int e = 0; e < ap->rots[b].nrot; ++e) slots[4 * b + e] = ap->rots[b].param[e];
+  DEVICE_SCOPE(h);
+  HIPCHK(h, hipMalloc((void**)&ap->d_slot_param, slots.size() * sizeof(int)));
+  HIPCHK(h, hipMemcpy(ap->d_slot_param, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+  *out = ap.get();
+  h->adj_plans[key] = std::move(ap);
+  return BORNVI_OK;
+}
+
 bool valid_n_for_dense(int n) { return n >= 1 && n <= 17; }
 bool valid_ld(int n, long long ld) { return ld >= (1ll << n) && (ld & 1) == 0 && ld <= (1ll << n) + 4096; }
 
@@ -332,6 +426,7 @@ int bornvi_create(int device_ordinal, bornvi_handle* out) {
 void bornvi_destroy(bornvi_handle h) {
   if (!h) return;
   for (auto& kv : h->plans) free_plan(kv.second.get());
+  for (auto& kv : h->adj_plans) if (kv.second->d_slot_param) (void)hipFree(kv.second->d_slot_param);
   delete h;
 }
 
@@ -349,6 +444,11 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   if (!std::strcmp(name, "circuit_cus")) { h->circuit_cus = (int)value; return BORNVI_OK; }
   if (!std::strcmp(name, "prefix_share")) { h->prefix_share = (int)value; return BORNVI_OK; }
   if (!std::strcmp(name, "batched_quadform")) { h->batched_quadform = value ? 1 : 0; return BORNVI_OK; }
+  if (!std::strcmp(name, "grad_engine")) {
+    if (value != 0 && value != 1) return fail(h, BORNVI_ERR_INVALID, "grad_engine: 0 = parameter shift, 1 = adjoint");
+    h->grad_engine = (int)value;
+    return BORNVI_OK;
+  }
   if (!std::strcmp(name, "direct_stages")) { h->direct_stages = (int)value; return BORNVI_OK; }   // bits 2..: 1 + the only pass allowed (debug)
   if (!std::strcmp(name, "fast_workgroups_per_cu")) {
     if (value < 0 || value > 16) return fail(h, BORNVI_ERR_INVALID, "option value out of range");
@@ -443,7 +543,13 @@ size_t bornvi_paramshift_grad_workspace_bytes(bornvi_handle h, int ansatz, int n
   const int nb = 2 * (p_end - p_begin);
   const size_t c = bornvi_circuit_workspace_bytes(h, ansatz, n, layers, nb);
   if (!c) return 0;
-  return c + align_up((size_t)nb * ((size_t)8 << n), 256);
+  size_t b = c + align_up((size_t)nb * ((size_t)8 << n), 256);
+  if (h->grad_engine == 1) {      // adjoint: state + full gradient + the walk's workspace
+    const int P = num_params(ansatz, n, layers);
+    const size_t a = bornvi_adjoint_workspace_bytes(h, ansatz, n, layers);
+    if (a) b = std::max(b, align_up((size_t)16 << n, 256) + align_up((size_t)(P > 0 ? P : 1) * 8, 256) + a);
+  }
+  return b;
 }
 
 int bornvi_paramshift_grad(bornvi_handle h, int ansatz, int n, int layers, const double* theta, const double* dLdq,
@@ -453,6 +559,23 @@ int bornvi_paramshift_grad(bornvi_handle h, int ansatz, int n, int layers, const
   if (!theta || !dLdq || !grad) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   const int ns = p_end - p_begin;
   if (ns == 0) return BORNVI_OK;
+  if (h->grad_engine == 1) {
+    const int P = num_params(ansatz, n, layers);
+    if (P < 0 || p_begin < 0 || p_end > P) return fail(h, BORNVI_ERR_INVALID, "parameter range out of bounds");
+    if (!workspace || workspace_bytes < bornvi_paramshift_grad_workspace_bytes(h, ansatz, n, layers, p_begin, p_end))
+      return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+    const size_t sb = align_up((size_t)16 << n, 256), gb = align_up((size_t)P * 8, 256);
+    double* state = (double*)workspace;
+    double* gfull = (double*)((char*)workspace + sb);
+    void* aws = (char*)workspace + sb + gb;
+    int rc = bornvi_adjoint_state(h, ansatz, n, layers, theta, state, nullptr, aws, workspace_bytes - sb - gb, stream);
+    if (rc) return rc;
+    rc = bornvi_adjoint_vjp(h, ansatz, n, layers, theta, state, dLdq, gfull, aws, workspace_bytes - sb - gb, stream);
+    if (rc) return rc;
+    DEVICE_SCOPE(h);
+    HIPCHK(h, hipMemcpyAsync(grad, gfull + p_begin, (size_t)ns * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BORNVI_OK;
+  }
   const size_t probs_bytes = align_up((size_t)2 * ns * ((size_t)8 << n), 256);
   if (!workspace || workspace_bytes < probs_bytes + 512) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
   double* shifted = (double*)workspace;
@@ -715,6 +838,75 @@ int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, do
     return fail(h, BORNVI_ERR_INVALID, "bad argument");
   DEVICE_SCOPE(h);
   HIPCHK(h, launch_clip_cast(grad64, P, max_norm, grad32, total_norm, loss, found_inf, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+size_t bornvi_adjoint_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers) {
+  if (!h) return 0;
+  AdjPlan* ap = nullptr;
+  if (get_adj_plan(h, ansatz, n, layers, &ap)) return 0;
+  const size_t st = align_up((size_t)16 << n, 256);
+  return 256 + 4 * st + align_up((ap->rots.size() + 1) * (size_t)adjoint_workgroups(n) * 4 * sizeof(double), 256);
+}
+
+int bornvi_adjoint_state(bornvi_handle h, int ansatz, int n, int layers, const double* theta, double* state, double* probs,
+                         void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  AdjPlan* ap = nullptr;
+  int rc = get_adj_plan(h, ansatz, n, layers, &ap);
+  if (rc) return rc;
+  if (!state || (!theta && ap->n_params > 0)) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!workspace || workspace_bytes < bornvi_adjoint_workspace_bytes(h, ansatz, n, layers)) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  DEVICE_SCOPE(h);
+  double* other = (double*)((char*)workspace + 256);
+  const int nent = (int)ap->ents_fwd.size();
+  double* cur = (nent % 2 == 0) ? state : other;            // every entangler block swaps: end in `state`
+  double* alt = (nent % 2 == 0) ? other : state;
+  HIPCHK(h, launch_adj_init(cur, n, st));
+  for (const AdjPlan::Step& s : ap->steps) {
+    if (s.is_rot) {
+      HIPCHK(h, launch_adj_rot_forward(cur, n, ap->rots[(size_t)s.index], theta, st));
+    } else {
+      HIPCHK(h, launch_adj_entangle(cur, alt, nullptr, nullptr, n, ap->ents_fwd[(size_t)s.index], 0, st));
+      std::swap(cur, alt);
+    }
+  }
+  if (probs) HIPCHK(h, launch_born_probs(state, probs, n, 1, st));
+  return BORNVI_OK;
+}
+
+int bornvi_adjoint_vjp(bornvi_handle h, int ansatz, int n, int layers, const double* theta, const double* state,
+                       const double* dLdq, double* grad, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  AdjPlan* ap = nullptr;
+  int rc = get_adj_plan(h, ansatz, n, layers, &ap);
+  if (rc) return rc;
+  if (ap->n_params == 0) return BORNVI_OK;
+  if (!state || !dLdq || !grad || !theta) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  if (!workspace || workspace_bytes < bornvi_adjoint_workspace_bytes(h, ansatz, n, layers)) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  DEVICE_SCOPE(h);
+  const size_t sb = align_up((size_t)16 << n, 256);
+  char* base = (char*)workspace + 256;
+  double* phi = (double*)base;
+  double* phi2 = (double*)(base + sb);
+  double* lam = (double*)(base + 2 * sb);
+  double* lam2 = (double*)(base + 3 * sb);
+  double* partials = (double*)(base + 4 * sb);
+  const int nwg = adjoint_workgroups(n);
+  HIPCHK(h, hipMemcpyAsync(phi, state, (size_t)16 << n, hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, launch_adj_lambda(state, dLdq, lam, n, st));
+  for (auto it = ap->steps.rbegin(); it != ap->steps.rend(); ++it) {
+    if (it->is_rot) {
+      HIPCHK(h, launch_adj_rot_backward(phi, lam, n, ap->rots[(size_t)it->index], theta, partials + (size_t)it->index * nwg * 4, st));
+    } else {
+      HIPCHK(h, launch_adj_entangle(phi, phi2, lam, lam2, n, ap->ents_bwd[(size_t)it->index], 1, st));
+      std::swap(phi, phi2);
+      std::swap(lam, lam2);
+    }
+  }
+  HIPCHK(h, launch_adj_reduce(partials, ap->d_slot_param, 4 * (int)ap->rots.size(), nwg, grad, st));
   return BORNVI_OK;
 }
 

@@ -39,6 +39,28 @@ hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g3
                             float* found_inf, hipStream_t st);
 hipError_t launch_dldq(const double* y, const double* ksd2, int n, double* dLdq, double* loss_out, hipStream_t st);
 
+// ---- adjoint differentiation (kernels_adjoint.hip): gate-block walks over one / two states ------------
+struct AdjRotBlock {      // consecutive one-qubit gates of one wire, applied e = 0 first (kinds: plan.hpp GateKind)
+  int wire, nrot;
+  int kind[4];
+  int param[4];           // parameter index or -1
+};
+constexpr int ADJ_MAX_CZ = 136;     // CZ gates of one entangler block (all_to_all at n = 17: 136 pairs)
+struct AdjEntangler {     // psi'[y] = s(y) psi[A y]: rows of A over the PHYSICAL index bits, CZ signs on linear functions of y
+  unsigned row[32];       // bit b of x = parity(y & row[b])
+  int ncz;
+  unsigned za[ADJ_MAX_CZ], zb[ADJ_MAX_CZ];
+};
+int adjoint_workgroups(int n);   // workgroups of a rotation-block launch (partials per block = 4 * this)
+hipError_t launch_adj_init(double* state, int n, hipStream_t st);
+hipError_t launch_adj_rot_forward(double* state, int n, const AdjRotBlock& blk, const double* theta, hipStream_t st);
+hipError_t launch_adj_rot_backward(double* phi, double* lam, int n, const AdjRotBlock& blk, const double* theta, double* partials,
+                                   hipStream_t st);
+hipError_t launch_adj_entangle(const double* in, double* out, const double* in2, double* out2, int n, const AdjEntangler& E,
+                               int sign_on_src, hipStream_t st);
+hipError_t launch_adj_lambda(const double* psi, const double* w, double* lam, int n, hipStream_t st);
+hipError_t launch_adj_reduce(const double* partials, const int* slot_param, int nslots, int nwg, double* grad, hipStream_t st);
+
 // ---- Stein ----------------------------------------------------------------------------------------
 hipError_t launch_score(const bornvi_bn_desc& bn, int n, double* S, double* pxz, hipStream_t st);
 // `ld`: row pitch of K in doubles (>= 2^n, even)

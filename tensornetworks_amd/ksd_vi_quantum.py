@@ -126,6 +126,11 @@ class KSDVariationalInference:
         #   None         = False.  `choose_overlap()` decides between False and "partition" by measurement.
         self.overlap_streams = None
         self.overlap_choice = None
+        # Gradient engine.  "paramshift" (default) = the reference's rule: 2P shifted circuit evaluations
+        # (diff_method="parameter-shift", quantum_born_machine.py:58).  "adjoint" = OPT-IN extra:
+        # one forward and one backward walk over the gates (bornvi_adjoint_state / _vjp) -- the same gradient to
+        # rounding from about three circuit evaluations; every rank computes it whole (nothing to shard).
+        self.grad_engine = "paramshift"
         self.gram_placement_tries = 1       # (> 1: build that many copies of a dense K_p >= 1 GiB and keep the one the
                                             # contraction streams fastest -- the round-1 workaround, off by default)
         self.gram_placement = None          # {"contraction_ms_per_try": [...], "kept": index} of the last _prepare_stein
@@ -335,6 +340,17 @@ class KSDVariationalInference:
         rank, ws = shard.world(self.process_group)
         lo, hi, step = shard.shard_params(P, rank, ws)
         n_local = len(range(lo, hi, step))
+        if self.grad_engine == "adjoint":
+            with self._timed("circuits"):
+                state, q = backend.adjoint_state(at, n, L, theta64)
+            with self._timed("stein"):
+                ksd2, y = self._stein_contract(q)
+            with self._timed("finish"):
+                loss, _, dldq = backend.ksd_grad_finish(n, None, 0, y, ksd2, want_dldq=True)
+                grad = backend.adjoint_vjp(at, n, L, theta64, state, dldq)
+            return loss, grad, q
+        if self.grad_engine != "paramshift":
+            raise ValueError("grad_engine must be 'paramshift' or 'adjoint'")
         overlap = self.overlap_streams
         if overlap is None:
             overlap = False

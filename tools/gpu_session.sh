@@ -22,6 +22,7 @@ sym() {
     grep -v amdgpu.ids gpurun_out/r2_sym_probe_$v.log
   done
 }
+tests_adj() { run 600 r2_gpu_tests_adj.log python -m pytest tests/test_gpu_adjoint.py -m gpu -x -q; tail -n 25 gpurun_out/r2_gpu_tests_adj.log; }
 tests_stein() { run 600 r2_gpu_tests_stein.log python -m pytest tests/test_gpu_stein.py tests/test_gpu_shard.py tests/test_gpu_trainer.py -m gpu -x -q; tail -n 15 gpurun_out/r2_gpu_tests_stein.log; }
 tests() { run 900 r2_gpu_tests.log python -m pytest tests -m gpu -x -q; tail -n 30 gpurun_out/r2_gpu_tests.log; }
 bench() { run 600 r2_bench.log python bench.py --steps 20 --warmup 5; grep '^{' gpurun_out/r2_bench.log > gpurun_out/r2_bench.json; tail -c 3000 gpurun_out/r2_bench.log; }
