@@ -303,16 +303,22 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
     precompute_s = time.perf_counter() - t0
     if args.overlap < 0:
         vi.choose_overlap()
-    opt_state = vi.make_optimizer(0.005, warmup + steps * 64, True, "adam", (0.9, 0.999))
+    use_graph = (args.graph == 1 or (args.graph < 0 and n <= 13)) and not args.host_sync and D.world == 1 and args.overlap == 0
+    opt_state = vi.make_optimizer(0.005, warmup + steps * 64, True, "adam", (0.9, 0.999), capturable=use_graph)
     clip = 10.0
     # --host-sync 1: every step ends with loss.item() like the reference's epoch (the GPU idles while the host
     # handles it); 0 (default): the same steps with the read-back of the K losses deferred to the end of the repeat
     # (NaN/Inf guard on the device), so the K steps run back to back
     step_fn = vi.training_step if args.host_sync else vi.training_step_async
     losses = []
-    for _ in range(warmup):
-        losses.append(step_fn(*opt_state, clip)[0])
-    vi.timers = {}
+    if use_graph:
+        # latency-bound sizes: the whole step (circuits, contraction, gradient, clip, Adam) replayed from ONE HIP graph
+        graphed = vi.make_graphed_step(*opt_state, clip, warmup=max(3, warmup))
+        step_fn = lambda params, opt, sched, clip_: tuple(t.clone() if i == 0 else t for i, t in enumerate(graphed()))
+    else:
+        for _ in range(warmup):
+            losses.append(step_fn(*opt_state, clip)[0])
+    vi.timers = None if use_graph else {}
     elapsed = []
     first, ls = run_repeat(vi, step_fn, opt_state, clip, steps, D, dev)
     elapsed.append(first)
@@ -323,11 +329,17 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
         elapsed.append(e)
         losses += ls
     timers = vi.timers
+    if use_graph:          # phase spans cannot be recorded inside a graph: take them from a few eager steps afterwards
+        vi.timers = {}
+        for _ in range(5):
+            vi.training_step_async(*opt_state, clip)
+        torch.cuda.synchronize(dev)
+        timers = vi.timers
     vi.timers = None
     # labelled extra: the same K steps with the other setting of prefix sharing (bit-identical shifted distributions,
     # fewer circuit-passes); not part of `value`
     extra_share = None
-    if want_extras:
+    if want_extras and not use_graph:
         backend.set_option(dev, "prefix_share", 0 if args.prefix_share else 1)
         for _ in range(2):
             step_fn(*opt_state, clip)
@@ -340,7 +352,21 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
                                "circuit starts from the base circuit's state at the first pass its parameter touches; rows bit-identical"}
         vi.timers = None
         backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
-    return {"vi": vi, "P": P, "theta0": theta0, "elapsed": elapsed, "timers": timers, "losses": losses,
+    extra_adjoint = None
+    if want_extras and D.world == 1:
+        # labelled extra: the same step with the OPT-IN adjoint gradient engine (one forward + one backward walk over
+        # the gates instead of 2P shifted circuits; same gradient to rounding); not part of `value`
+        vi.grad_engine = "adjoint"
+        astep = vi.training_step_async
+        for _ in range(2):
+            astep(*opt_state, clip)
+        e3, _ = run_repeat(vi, astep, opt_state, clip, steps, D, dev)
+        vi.grad_engine = "paramshift"
+        extra_adjoint = {"grad_engine": "adjoint", "steps_per_sec": round(steps / e3, 4), "ms_per_step": round(1e3 * e3 / steps, 4),
+                         "note": "opt-in (SURVEY 8(f) row 4): adjoint differentiation replaces the 2P parameter-shift circuit "
+                                 "evaluations; eager launches, gate-block kernels (kernels_adjoint.hip)"}
+    return {"vi": vi, "P": P, "theta0": theta0, "elapsed": elapsed, "timers": timers, "losses": losses, "graph": use_graph,
+            "extra_adjoint": extra_adjoint,
             "precompute_s": precompute_s, "extra_share": extra_share, "n": n, "layers": layers, "ansatz": ansatz,
             "gram_mode": gram_mode}
 
@@ -488,6 +514,9 @@ def main(argv=None):
                     help="1: headline WITH prefix sharing of the shifted circuits (opt-in extra, SURVEY 8(f) row 4); the default "
                          "headline runs all 2P+1 circuits in full and reports the shared variant under 'extras'")
     ap.add_argument("--no-extras", action="store_true", help="skip the labelled extra leg (profiling runs: one variant per trace)")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: replay the step from one HIP graph (make_graphed_step); 0: eager launches; -1 (default): graph for "
+                         "the latency-bound sizes n <= 13, eager above")
     ap.add_argument("--overlap", type=int, default=0,
                     help="how circuits and contraction share the GPU: 0 in sequence (default), 1 second plain stream, 2 two "
                          "CU-masked streams (half the CUs each), -1 measured choice between 0 and 2 (choose_overlap)")
@@ -544,7 +573,9 @@ def main(argv=None):
                        "optimizer": "adam lr=0.005 cosine clip=10",
                        "parallelism": f"paramshift + gram {'strip-pair' if vi._K_pairs is not None else 'row'} shard x{world}",
                        "dist_backend": D.backend if world > 1 else None},
-            "repeats": rep, "roofline": roof, "kernels": kern, "extras": {"prefix_sharing": m["extra_share"]},
+            "repeats": rep, "roofline": roof, "kernels": kern,
+            "extras": {"prefix_sharing": m["extra_share"], "adjoint_engine": m["extra_adjoint"]},
+            "launch": "one HIP graph replay per step (make_graphed_step)" if m["graph"] else "eager kernel launches",
             "overlap": {"mode": {False: "sequential", True: "second stream", "partition": "cu-partition"}[vi.overlap_streams],
                         "measured_choice": vi.overlap_choice},
             "gram_placement": vi.gram_placement,

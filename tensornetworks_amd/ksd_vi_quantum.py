@@ -425,15 +425,24 @@ class KSDVariationalInference:
         return loss, grad, q
 
     def make_optimizer(self, lr_born_machine, num_epochs, use_lr_scheduler=True, optimizer_type="adam",
-                       adam_betas=(0.9, 0.999)):
-        """Optimiser and scheduler exactly as the reference builds them (ksd_vi_quantum.py:92-103)."""
+                       adam_betas=(0.9, 0.999), capturable=False):
+        """Optimiser and scheduler exactly as the reference builds them (ksd_vi_quantum.py:92-103).
+        capturable=True (Adam on the GPU only): the learning rate lives in a device tensor and the step counter on the
+        device, so that the whole step can be replayed from a HIP graph (`make_graphed_step`); same update rule."""
         params = list(self.born_machine.parameters())
         # same optimisers and hyper-parameters as the reference; when theta lives on the GPU the single-kernel
         # ("fused") implementation of the same torch.optim class is selected: identical update rule, ~0.1 ms
         # less host time per step
         fused = {"fused": True} if all(p.is_cuda for p in params) else {}
+        if capturable:
+            if optimizer_type != "adam" or not fused:
+                raise backend.BornviError("a graph-capturable step needs Adam with theta on the GPU")
+            fused["capturable"] = True
+            lr_born_machine_arg = torch.tensor(float(lr_born_machine), dtype=torch.float32, device=params[0].device)
+        else:
+            lr_born_machine_arg = lr_born_machine
         if optimizer_type == "adam":
-            optimizer_born = optim.Adam(params, lr=lr_born_machine, betas=adam_betas, **fused)
+            optimizer_born = optim.Adam(params, lr=lr_born_machine_arg, betas=adam_betas, **fused)
         elif optimizer_type == "sgd":
             optimizer_born = optim.SGD(params, lr=lr_born_machine, momentum=0.9, **fused)
         else:
@@ -466,6 +475,59 @@ class KSDVariationalInference:
         if scheduler is not None:
             scheduler.step()
         return loss_t, grad_norm, q
+
+    def make_graphed_step(self, params, optimizer_born, scheduler, gradient_clip_norm, warmup=3):
+        """The epoch body of `training_step_async` captured ONCE into a HIP graph (torch.cuda.CUDAGraph: our kernels
+        are launched on torch's current stream, so the capture records them together with the cast, the fused Adam
+        kernel and the guard) and replayed per step: one graph launch instead of ~15 kernel launches and their host
+        work.  For the latency-bound sizes (n <= 13: BASELINE config 2 spends its step in launch overhead, SURVEY
+        section 7.4).  Returns step() -> (loss [1], grad_norm, q): tensors OWNED BY THE GRAPH, overwritten by the next
+        step (clone what must be kept).  Needs `make_optimizer(..., capturable=True)`; `warmup` eager steps run first
+        (they are real optimiser steps).  The scheduler advances on the host after each replay (it fills the
+        learning-rate tensor the captured Adam kernel reads)."""
+        theta = self.born_machine.theta
+        if not (theta.is_cuda and theta.dtype == torch.float32 and len(params) == 1 and optimizer_born.defaults.get("capturable")):
+            raise backend.BornviError("make_graphed_step needs a float32 theta on the GPU and make_optimizer(capturable=True)")
+        if self.timers is not None:
+            raise backend.BornviError("event timers cannot be recorded inside a graph capture: set timers = None")
+        dev = theta.device
+        if theta.grad is None:
+            theta.grad = torch.zeros_like(theta)
+        found = torch.zeros((), dtype=torch.float32, device=dev)
+
+        def body():
+            loss_t, grad64, q = self.ksd_and_grad()
+            g32, grad_norm, found_inf = backend.clip_cast_grad_guard(grad64, gradient_clip_norm, loss_t)
+            theta.grad.copy_(g32)
+            found.copy_(found_inf)
+            optimizer_born.found_inf = found
+            try:
+                optimizer_born.step()
+            finally:
+                del optimizer_born.found_inf
+            return loss_t, grad_norm, q
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):      # plans, workspaces and optimiser state exist before the capture
+                body()
+                if scheduler is not None:
+                    scheduler.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = body()
+
+        def step():
+            graph.replay()
+            if scheduler is not None:
+                scheduler.step()
+            return out
+
+        step.graph = graph
+        return step
 
     def training_step(self, params, optimizer_born, scheduler, gradient_clip_norm):
         """One epoch body (reference :111-161) without the logging: device step, NaN/Inf guard, clip,

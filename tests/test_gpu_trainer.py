@@ -293,3 +293,38 @@ def test_clip_cast_guard_flags_nonfinite_loss(dev):
         assert float(found) == want, (val, float(found))
     np.testing.assert_allclose(g32_ref.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-6)
     np.testing.assert_allclose(float(norm_ref), float(tn), rtol=1e-6)
+
+
+def test_graphed_step_replays_the_async_step(dev):
+    """make_graphed_step: BASELINE config 2's step (n = 8, L = 4, dense) captured once into a HIP graph and replayed --
+    the same kernels in the same order, so losses and theta are the bits of the eager training_step_async trajectory
+    (Adam + cosine schedule + clip, the NaN/Inf guard on the device)."""
+    n, L = 8, 4
+    bn, lat, obs, x = synthetic_network(n, 0)
+    runs = []
+    for graphed in (False, True):
+        vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=21, gram_mode="dense")
+        vi._prepare_stein(x)
+        params, opt, sched = vi.make_optimizer(0.01, 9, True, "adam", (0.9, 0.999), capturable=True)
+        losses = []
+        if graphed:
+            step = vi.make_graphed_step(params, opt, sched, 10.0, warmup=3)      # 3 eager steps, then replays
+            for _ in range(6):
+                l, gn, q = step()
+                losses.append(float(l))
+            assert abs(float(q.sum()) - 1.0) < 1e-12 and float(gn) > 0
+        else:
+            for i in range(9):
+                l, gn, q = vi.training_step_async(params, opt, sched, 10.0)
+                if i >= 3:
+                    losses.append(float(l))
+        runs.append((losses, vi.born_machine.theta.detach().cpu().numpy().copy(), float(sched.get_last_lr()[0])))
+    assert runs[0][0] == runs[1][0]
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert runs[0][2] == runs[1][2]
+    assert runs[0][0][-1] < runs[0][0][0]            # it trains
+    with pytest.raises(Exception):
+        vi2 = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=21, gram_mode="dense")
+        vi2._prepare_stein(x)
+        p2, o2, s2 = vi2.make_optimizer(0.01, 9, True, "adam", (0.9, 0.999))        # not capturable
+        vi2.make_graphed_step(p2, o2, s2, 10.0)

@@ -22,6 +22,9 @@ sym() {
     grep -v amdgpu.ids gpurun_out/r2_sym_probe_$v.log
   done
 }
+tests_graph() { run 600 r2_gpu_tests_graph.log python -m pytest tests/test_gpu_trainer.py -m gpu -x -q -k "graphed or async"; tail -n 25 gpurun_out/r2_gpu_tests_graph.log; }
+bench_small() { for w in n8_L4_dense n12_L4_dense; do run 300 r2_bench_$w.log python bench.py --steps 200 --warmup 5 --workload $w --no-cpu-baseline --no-gate-bench --series none; grep '^{' gpurun_out/r2_bench_$w.log > gpurun_out/r2_bench_$w.json; python -c "
+import json; r=json.load(open('gpurun_out/r2_bench_$w.json')); print('$w', r['value'], 'steps/s', r['ms_per_step'], 'ms', r['launch'], r['extras']['adjoint_engine'])"; done; }
 tests_adj() { run 600 r2_gpu_tests_adj.log python -m pytest tests/test_gpu_adjoint.py -m gpu -x -q; tail -n 25 gpurun_out/r2_gpu_tests_adj.log; }
 tests_stein() { run 600 r2_gpu_tests_stein.log python -m pytest tests/test_gpu_stein.py tests/test_gpu_shard.py tests/test_gpu_trainer.py -m gpu -x -q; tail -n 15 gpurun_out/r2_gpu_tests_stein.log; }
 tests() { run 900 r2_gpu_tests.log python -m pytest tests -m gpu -x -q; tail -n 30 gpurun_out/r2_gpu_tests.log; }
