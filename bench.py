@@ -49,6 +49,7 @@ WORKLOADS = {
     "n20_L8_kron": (20, 8, "hardware_efficient", "kron"),
     "n12_L4_dense": (12, 4, "hardware_efficient", "dense"),
 }
+ADV_WORKLOADS = {"adv_n12_b65536": (12, 4, 65536)}     # BASELINE config 5: (n, layers, REINFORCE batch)
 SERIES_WORKLOAD = "n20_L8_kron"     # BASELINE config 4: reported beside the headline at every N
 
 
@@ -491,13 +492,63 @@ def summarize(m, steps):
                  "ms_per_step_max": round(per[-1], 4), "timed_seconds_total": round(float(sum(m["elapsed"])), 3)}
 
 
+def bench_adversarial(args, dev, D):
+    """BASELINE config 5: adversarial-VI epochs/s at n = 12 qubits, REINFORCE batch 65,536, classifier
+    forward/backward, one classifier step + one Born-machine step per epoch (the reference's defaults,
+    adversarial_vi.py:104-107).  A step = one epoch; phases from event spans inside the trainer."""
+    import contextlib
+    import io
+    from tensornetworks_amd.adversarial_vi import AdversarialVariationalInference
+    from tensornetworks_amd.bayesian_network import synthetic_network
+    n, layers, batch = ADV_WORKLOADS[args.workload]
+    # milder CPTs than the KSD benchmarks: with U(0.01, 0.99) tables some states have p(z) < 1e-9, for which the
+    # reference's rule (adversarial_vi.py:91-96) makes the reward infinite
+    bn, lat, obs, x = synthetic_network(n, 0, p_low=0.25, p_high=0.75)
+    torch.manual_seed(0)
+    adv = AdversarialVariationalInference(bn, lat, obs, born_machine_config={'ansatz_layers': layers, 'conditioning_dim': 0},
+                                          classifier_config={}, device=str(dev))
+    kw = dict(batch_size=batch, lr_born_machine=0.003, lr_classifier=0.03, k_classifier_steps=1, k_born_steps=1, verbose=False,
+              adam_betas=(0.5, 0.999))
+    with contextlib.redirect_stdout(io.StringIO()):
+        adv.train(x, num_epochs=max(2, args.warmup), **kw)
+        elapsed = []
+        hist = None
+        adv.timers = {}
+        for _ in range(max(3, args.repeats)):
+            D.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            hist = adv.train(x, num_epochs=args.steps, **kw)
+            torch.cuda.synchronize(dev)
+            D.barrier()
+            elapsed.append(D.max_over_ranks(time.perf_counter() - t0))
+    per = sorted(1e3 * e / args.steps for e in elapsed)
+    med = float(np.median(per))
+    P = adv.born_machine.num_ansatz_params
+    rec = {"metric": "adversarial_vi_epochs_per_sec", "value": round(1e3 / med, 4), "unit": "epochs/s", "n_gpus": D.world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(med, 4), "higher_is_better": True, "scaling": "replicas only",
+           "vs_baseline": None, "dtype": "f64 circuits / f32 classifier", "data": "synthetic",
+           "config": {"workload": args.workload, "n_qubits": n, "layers": layers, "params": P, "reinforce_batch": batch,
+                      "k_classifier_steps": 1, "k_born_steps": 1, "circuits_per_epoch": 2 + 2 * P,
+                      "classifier": "BinaryClassifierMLP defaults (classifier_pytorch.py:27-41)",
+                      "bayesian_network": f"synthetic n={n} seed=0, CPT entries U(0.25, 0.75)"},
+           "repeats": {"n": len(per), "ms_per_step_median": round(med, 4), "ms_per_step_min": round(per[0], 4), "ms_per_step_max": round(per[-1], 4)},
+           "phase_ms": phase_means(adv.timers), "roofline": None, "cpu_baseline": None,
+           "note": "torch-op composition around the HIP circuit engine (sampling, table gathers, MLP): no kernel of its own, "
+                   "so no roofline row; the Born step's backward is 2P parameter-shift circuits",
+           "loss_last": {"classifier": hist['loss_classifier'][-1], "born_machine": hist['loss_born_machine'][-1]}}
+    if D.rank == 0:
+        print(json.dumps(rec))
+    D.close()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K timed steps (0 = at least 5 and at least 2 s in all)")
-    ap.add_argument("--workload", default="n16_L6_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="n16_L6_dense", choices=sorted(WORKLOADS) + sorted(ADV_WORKLOADS))
     ap.add_argument("--series", default="auto", help="'auto': also measure n20_L8_kron (BASELINE config 4) beside the default "
                                                       "workload; 'none'; or a workload name")
     ap.add_argument("--dist-selftest", action="store_true", help="N > 1: check the sharded step against an un-sharded recomputation first")
@@ -548,6 +599,9 @@ def main(argv=None):
     if args.fast_wgs_per_cu >= 0:
         backend.set_option(dev, "fast_workgroups_per_cu", args.fast_wgs_per_cu)
     backend.set_option(dev, "prefix_share", 1 if args.prefix_share else 0)
+
+    if args.workload in ADV_WORKLOADS:
+        return bench_adversarial(args, dev, D)
 
     selftest = dist_selftest(dev, D) if (args.dist_selftest and world > 1) else None
 

@@ -62,6 +62,9 @@ class AdversarialVariationalInference:
         self._shifts = torch.arange(n - 1, -1, -1, device=device)
         self._log_p_x_given_z = None
         self._log_p_key = None
+        self._label_cache = None
+        self._baseline = None
+        self.timers = None      # optional {phase: [(start, end) events]} filled by the steps (bench.py)
 
     # reference attributes kept lazily (2^n Python objects)
     @property
@@ -107,31 +110,111 @@ class AdversarialVariationalInference:
         """reference :60-102 -- a table gather instead of one network enumeration per sample."""
         return self._log_p_table(x_obs_tensor)[self._index(z_samples_tensor)]
 
+    # ---- one classifier step / one Born-machine step, device-resident (no host read-back inside) ----------------------
+    def _spans(self, name):
+        from .ksd_vi_quantum import _EventSpan
+        return _EventSpan(self.timers if torch.device(self.device).type == "cuda" else None, name)
+
+    def _clf_inputs(self, z, x_obs_tensor, with_x):
+        if with_x:
+            return torch.cat((z, x_obs_tensor.unsqueeze(0).expand(z.shape[0], -1)), dim=1)
+        return z
+
+    def _classifier_step(self, batch_size, x_obs_tensor, with_x, optimizer_classifier, criterion, clip):
+        """reference :151-181: BCE on Born samples (label 1) against prior samples (label 0); one q_theta evaluation."""
+        optimizer_classifier.zero_grad()
+        with self._spans("sample"):
+            with torch.no_grad():
+                q = self.born_machine.get_probabilities().detach()
+                z_from_born = self._bits(torch.multinomial(q / q.sum(), batch_size, replacement=True).to(self.device))
+            z_from_prior = self._sample_from_prior_z(batch_size)
+        with self._spans("classifier"):
+            all_inputs = torch.cat((self._clf_inputs(z_from_born, x_obs_tensor, with_x),
+                                    self._clf_inputs(z_from_prior, x_obs_tensor, with_x)), dim=0)
+            labels = self._labels(batch_size)
+            loss_d = criterion(self.classifier(all_inputs), labels)
+            loss_d.backward()
+            grad_norm_d = nn_utils.clip_grad_norm_(self.classifier.parameters(), clip)
+            optimizer_classifier.step()
+        return loss_d.detach(), grad_norm_d
+
+    def _labels(self, batch_size):
+        if self._label_cache is None or self._label_cache.shape[0] != 2 * batch_size:
+            self._label_cache = torch.cat((torch.ones(batch_size, 1, device=self.device),
+                                           torch.zeros(batch_size, 1, device=self.device)), dim=0)
+        return self._label_cache
+
+    def _born_step(self, batch_size, x_obs_tensor, with_x, optimizer_born, clip, baseline_decay, first):
+        """reference :184-231: REINFORCE with a running baseline and an entropy bonus.  ONE differentiable q_theta
+        evaluation serves the sampling and log q (the reference runs the circuit twice); the baseline is a device scalar;
+        a NaN / Inf loss skips the update on the device (the fused optimiser's found_inf) -- nothing is read back.
+        Returns (loss [0-dim], grad norm [0-dim], finite flag [0-dim bool])."""
+        optimizer_born.zero_grad()
+        theta = self.born_machine.theta
+        with self._spans("born_forward"):
+            q = self.born_machine.get_probabilities()                 # float64 [2^n], differentiable (parameter shift)
+            with torch.no_grad():
+                qd = q.detach()
+                idx = torch.multinomial(qd / qd.sum(), batch_size, replacement=True)
+                z_q = self._bits(idx.to(self.device))
+                logit_d = self.classifier(self._clf_inputs(z_q, x_obs_tensor, with_x)).squeeze()
+                log_p = self._log_p_table(x_obs_tensor)[idx.to(self.device)]
+                raw_reward = logit_d - log_p
+                mean_reward = raw_reward.mean()
+                if first:
+                    self._baseline = mean_reward.clone()
+                else:
+                    self._baseline = baseline_decay * self._baseline + (1 - baseline_decay) * mean_reward
+                reinforce_reward = raw_reward - self._baseline
+            log_q = torch.log(q.clamp(min=1e-9))[idx].to(self.device)
+            loss_q = (log_q * reinforce_reward - (-0.01 * log_q)).mean()
+        with self._spans("born_backward"):
+            finite = torch.isfinite(loss_q.detach())
+            fused_ok = theta.is_cuda and optimizer_born.defaults.get("fused")
+            if fused_ok:
+                loss_q.backward()                                     # 2P parameter-shift circuits on the HIP engine
+                grad_norm_q = nn_utils.clip_grad_norm_(self.born_machine.parameters(), clip)
+                optimizer_born.found_inf = (~finite).to(torch.float32)     # skip the update on the device
+                try:
+                    optimizer_born.step()
+                finally:
+                    del optimizer_born.found_inf
+            elif bool(finite):
+                loss_q.backward()
+                grad_norm_q = nn_utils.clip_grad_norm_(self.born_machine.parameters(), clip)
+                optimizer_born.step()
+            else:
+                grad_norm_q = None
+        return loss_q.detach(), grad_norm_q, finite
+
     def train(self, x_observation_dict, num_epochs, batch_size, lr_born_machine, lr_classifier,
               k_classifier_steps=1, k_born_steps=1, verbose=True, true_posterior_for_tvd=None,
               use_lr_scheduler=True, gradient_clip_norm=10.0, baseline_decay=0.99,
               optimizer_type="adam", adam_betas=(0.9, 0.999)):
-
+        """Same signature, history keys and messages as the reference (adversarial_vi.py:104-270).  The epoch runs
+        without host read-backs: losses and norms stay on the device and are fetched at the points where the reference
+        prints (every num_epochs // 20 epochs) and once at the end; the "NaN or Inf" warning is therefore printed at
+        the next such point instead of inside the step."""
         if self.num_observed_vars > 0 and set(x_observation_dict.keys()) != set(self.observed_vars_names):
             raise ValueError("Keys in x_observation_dict must match self.observed_vars_names.")
 
         x_obs_list = [x_observation_dict[name] for name in self.observed_vars_names] if self.num_observed_vars > 0 else []
         x_obs_tensor = torch.tensor(x_obs_list, dtype=torch.float32, device=self.device)
 
-        born_machine_x_condition = None
         if self.born_machine.conditioning_dim > 0:
             if self.num_observed_vars == 0:
                 raise ValueError("Born machine is conditional but no observed vars specified.")
             if self.born_machine.conditioning_dim != self.num_observed_vars:
                 raise ValueError("Born machine conditioning_dim must match num_observed_vars if used.")
-            born_machine_x_condition = x_obs_tensor
 
+        on_gpu = torch.device(self.device).type == "cuda"
+        fused = {"fused": True} if on_gpu else {}
         if optimizer_type == "adam":
-            optimizer_born = optim.Adam(self.born_machine.parameters(), lr=lr_born_machine, betas=adam_betas)
-            optimizer_classifier = optim.Adam(self.classifier.parameters(), lr=lr_classifier, betas=adam_betas)
+            optimizer_born = optim.Adam(self.born_machine.parameters(), lr=lr_born_machine, betas=adam_betas, **fused)
+            optimizer_classifier = optim.Adam(self.classifier.parameters(), lr=lr_classifier, betas=adam_betas, **fused)
         else:
-            optimizer_born = optim.SGD(self.born_machine.parameters(), lr=lr_born_machine, momentum=0.9)
-            optimizer_classifier = optim.SGD(self.classifier.parameters(), lr=lr_classifier, momentum=0.9)
+            optimizer_born = optim.SGD(self.born_machine.parameters(), lr=lr_born_machine, momentum=0.9, **fused)
+            optimizer_classifier = optim.SGD(self.classifier.parameters(), lr=lr_classifier, momentum=0.9, **fused)
 
         scheduler_born = scheduler_classifier = None
         if use_lr_scheduler:
@@ -139,64 +222,40 @@ class AdversarialVariationalInference:
             scheduler_classifier = optim.lr_scheduler.CosineAnnealingLR(optimizer_classifier, T_max=num_epochs, eta_min=lr_classifier / 10)
 
         criterion_classifier = nn.BCEWithLogitsLoss()
-        running_baseline = 0.0
-        history = {'loss_classifier': [], 'loss_born_machine': [], 'tvd': [], 'grad_norm_born': [], 'grad_norm_classifier': []}
+        self._baseline = torch.zeros((), device=self.device)
+        self._label_cache = None
+        self._log_p_table(x_obs_tensor)                    # built once, outside the epochs
+        dev_hist = {'loss_classifier': [], 'loss_born_machine': [], 'grad_norm_born': [], 'grad_norm_classifier': []}
+        tvds = []
         best_tvd = float('inf')
         best_born_params = best_classifier_params = None
         in_features = self.classifier.network[0].in_features
         with_x = in_features == self.num_latent_vars + self.num_observed_vars and self.num_observed_vars > 0
         if not with_x and in_features != self.num_latent_vars:
             raise ValueError("Classifier input dimension mismatch.")
-        loss_d = grad_norm_d = loss_q = grad_norm_q = None
+        nan_t = torch.full((), float('nan'), device=self.device)
+        zero_t = torch.zeros((), device=self.device)
+        loss_d = grad_norm_d = None
+        skipped_seen = 0
+        skipped = torch.zeros((), dtype=torch.int64, device=self.device)
+        tvd_on_device = torch.is_tensor(true_posterior_for_tvd)
 
         for epoch in range(num_epochs):
-            # --- classifier steps (reference :151-181)
             for _ in range(k_classifier_steps):
-                optimizer_classifier.zero_grad()
-                z_from_born = self.born_machine.sample(batch_size, x_condition=born_machine_x_condition)
-                z_from_prior = self._sample_from_prior_z(batch_size)
-                if with_x:
-                    x_rep = x_obs_tensor.unsqueeze(0).repeat(batch_size, 1)
-                    inputs_born = torch.cat((z_from_born, x_rep), dim=1)
-                    inputs_prior = torch.cat((z_from_prior, x_rep), dim=1)
-                else:
-                    inputs_born, inputs_prior = z_from_born, z_from_prior
-                all_inputs = torch.cat((inputs_born, inputs_prior), dim=0)
-                all_labels = torch.cat((torch.ones(batch_size, 1, device=self.device),
-                                        torch.zeros(batch_size, 1, device=self.device)), dim=0)
-                loss_d = criterion_classifier(self.classifier(all_inputs), all_labels)
-                loss_d.backward()
-                grad_norm_d = nn_utils.clip_grad_norm_(self.classifier.parameters(), gradient_clip_norm)
-                optimizer_classifier.step()
-            history['loss_classifier'].append(loss_d.item())
-            history['grad_norm_classifier'].append(grad_norm_d.item())
+                loss_d, grad_norm_d = self._classifier_step(batch_size, x_obs_tensor, with_x, optimizer_classifier,
+                                                            criterion_classifier, gradient_clip_norm)
+            dev_hist['loss_classifier'].append(loss_d if loss_d is not None else nan_t)
+            dev_hist['grad_norm_classifier'].append(grad_norm_d.detach() if grad_norm_d is not None else zero_t)
 
-            # --- Born-machine steps: REINFORCE with running baseline and entropy bonus (reference :184-231)
+            loss_q = grad_norm_q = finite = None
             for _ in range(k_born_steps):
-                optimizer_born.zero_grad()
-                z_q = self.born_machine.sample(batch_size, x_condition=born_machine_x_condition)
-                if with_x:
-                    clf_in = torch.cat((z_q, x_obs_tensor.unsqueeze(0).repeat(batch_size, 1)), dim=1)
-                else:
-                    clf_in = z_q
-                logit_d = self.classifier(clf_in).squeeze()
-                log_p = self._get_log_p_x_given_z(x_obs_tensor, z_q)
-                raw_reward = logit_d - log_p
-                mean_reward = raw_reward.detach().mean().item()
-                running_baseline = mean_reward if epoch == 0 else baseline_decay * running_baseline + (1 - baseline_decay) * mean_reward
-                reinforce_reward = raw_reward - running_baseline
-                log_q = self.born_machine.get_log_q_z_x(z_q, born_machine_x_condition)
-                entropy_bonus = -0.01 * log_q
-                loss_q = (log_q * reinforce_reward.detach() - entropy_bonus).mean()
-                if torch.isnan(loss_q) or torch.isinf(loss_q):
-                    print(f"Warning: NaN or Inf encountered in Born machine loss. Skipping update.")
-                else:
-                    loss_q.backward()
-                    grad_norm_q = nn_utils.clip_grad_norm_(self.born_machine.parameters(), gradient_clip_norm)
-                    optimizer_born.step()
-            ok = loss_q is not None and not (torch.isnan(loss_q) or torch.isinf(loss_q))
-            history['loss_born_machine'].append(loss_q.item() if ok else np.nan)
-            history['grad_norm_born'].append(grad_norm_q.item() if grad_norm_q is not None else 0.0)
+                loss_q, gn, finite = self._born_step(batch_size, x_obs_tensor, with_x, optimizer_born, gradient_clip_norm,
+                                                     baseline_decay, first=(epoch == 0))
+                if gn is not None:
+                    grad_norm_q = gn
+                skipped = skipped + (~finite).to(torch.int64)
+            dev_hist['loss_born_machine'].append(torch.where(finite, loss_q, nan_t.to(loss_q.dtype)) if loss_q is not None else nan_t)
+            dev_hist['grad_norm_born'].append(grad_norm_q.detach() if grad_norm_q is not None else zero_t)
 
             if scheduler_born is not None:
                 scheduler_born.step()
@@ -204,23 +263,36 @@ class AdversarialVariationalInference:
                 scheduler_classifier.step()
 
             if true_posterior_for_tvd is not None:
-                tvd = calculate_tvd(true_posterior_for_tvd, self.born_machine.get_prob_dict(x_condition=born_machine_x_condition))
-                history['tvd'].append(tvd)
+                if tvd_on_device:                     # array form (stein_utils.true_posterior_table): stays on the device
+                    from .stein_utils import tvd_table
+                    q_now = self.born_machine.get_probabilities().detach()
+                    tvd = float(tvd_table(true_posterior_for_tvd.to(q_now.device), q_now))
+                else:
+                    tvd = calculate_tvd(true_posterior_for_tvd, self.born_machine.get_prob_dict())
+                tvds.append(tvd)
                 if tvd < best_tvd:
                     best_tvd = tvd
                     best_born_params = self.born_machine.state_dict()
                     best_classifier_params = self.classifier.state_dict()
             else:
-                history['tvd'].append(np.nan)
+                tvds.append(np.nan)
 
             if verbose and (epoch % max(1, num_epochs // 20) == 0 or epoch == num_epochs - 1):
-                log_msg = f"Epoch {epoch+1}/{num_epochs} | Loss D: {loss_d.item():.4f} | Loss G: {history['loss_born_machine'][-1]:.4f}"
+                n_skipped = int(skipped)                                   # (this epoch's one read-back)
+                for _ in range(n_skipped - skipped_seen):
+                    print(f"Warning: NaN or Inf encountered in Born machine loss. Skipping update.")
+                skipped_seen = n_skipped
+                log_msg = f"Epoch {epoch+1}/{num_epochs} | Loss D: {float(dev_hist['loss_classifier'][-1]):.4f} | Loss G: {float(dev_hist['loss_born_machine'][-1]):.4f}"
                 if scheduler_born is not None:
                     log_msg += f" | LR_G: {scheduler_born.get_last_lr()[0]:.6f}"
-                if true_posterior_for_tvd and not np.isnan(history['tvd'][-1]):
-                    log_msg += f" | TVD: {history['tvd'][-1]:.4f}"
+                if true_posterior_for_tvd is not None and len(true_posterior_for_tvd) and not np.isnan(tvds[-1]):
+                    log_msg += f" | TVD: {tvds[-1]:.4f}"
                 print(log_msg)
 
+        history = {k: (torch.stack([t.to(torch.float64).reshape(()) for t in v]).cpu().tolist() if v else []) for k, v in dev_hist.items()}
+        history['tvd'] = tvds
+        for _ in range(int(skipped) - skipped_seen):
+            print(f"Warning: NaN or Inf encountered in Born machine loss. Skipping update.")
         if best_born_params is not None and verbose:
             print(f"\nRestoring best parameters (TVD: {best_tvd:.6f})")
             self.born_machine.load_state_dict(best_born_params)
