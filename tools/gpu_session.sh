@@ -23,6 +23,11 @@ sym() {
   done
 }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
+profile() {
+  tools/prof_stats.sh r02_n16_L6_dense 2>&1 | tail -14
+  tools/prof_stats.sh r02_n20_L8_kron --workload n20_L8_kron 2>&1 | tail -8
+  tools/pmc_traffic.sh 2>&1 | tail -3
+}
 tests_advq() { run 600 r2_gpu_tests_adv.log python -m pytest tests/test_gpu_adversarial.py -m gpu -x -q; tail -n 25 gpurun_out/r2_gpu_tests_adv.log; }
 bench_adv() { run 300 r2_bench_adv.log python bench.py --steps 20 --warmup 3 --workload adv_n12_b65536; grep '^{' gpurun_out/r2_bench_adv.log > gpurun_out/r2_bench_adv.json; tail -c 1500 gpurun_out/r2_bench_adv.json; }
 tests_graph() { run 600 r2_gpu_tests_graph.log python -m pytest tests/test_gpu_trainer.py -m gpu -x -q -k "graphed or async"; tail -n 25 gpurun_out/r2_gpu_tests_graph.log; }

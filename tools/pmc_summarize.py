@@ -11,8 +11,9 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = sys.argv[1] if len(sys.argv) > 1 else "r01_pmc_traffic_n16_L6_dense.json"
+out = sys.argv[1] if len(sys.argv) > 1 else "r02_pmc_traffic_n16_L6_dense.json"
 note = sys.argv[2] if len(sys.argv) > 2 else ""
+commit = sys.argv[3] if len(sys.argv) > 3 else "?"
 
 
 def short(name):
@@ -24,7 +25,9 @@ def short(name):
 tot = {"FETCH_SIZE": collections.defaultdict(float), "WRITE_SIZE": collections.defaultdict(float)}
 cnt = {"FETCH_SIZE": collections.Counter(), "WRITE_SIZE": collections.Counter()}
 for c in tot:
-    for f in glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_traffic_{c}", "*", "*counter_collection.csv")):
+    files = glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_traffic_{c}", "*", "*counter_collection.csv"))
+    # (gpurun merges new files into gpurun_out without deleting older runs': take the newest run only)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
@@ -40,7 +43,12 @@ for k in sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"])):
     wb = tot["WRITE_SIZE"][k] * 1024 / nw if nw else 0.0
     kern[k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
                "launches_sampled": int(max(nf, nw))}
-rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench.py --steps 2 "
+# the plan these bytes belong to: bench.py shows the traffic only while the library still plans the same passes
+sys.path.insert(0, REPO)
+from tensornetworks_amd import _ext  # noqa: E402  (host-only planner entry point: no GPU needed)
+plan = _ext.plan_words(_ext.ANSATZ_IDS["hardware_efficient"], 16, 6, 0)
+signature = {"workload": "n16_L6_dense", "passes": int(plan[3]), "tile_bits": int(plan[2]), "commit": commit}
+rec = {"signature": signature, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench.py --steps 2 "
                  "--warmup 1, workload n16_L6_dense" + (" -- " + note if note else ""),
        "correction": "gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read -> fetch bytes = 2 * FETCH_SIZE * 1024; "
                      "WRITE_SIZE * 1024 exact (MI355X_MICROARCH.md, HBM)",
