@@ -849,7 +849,7 @@ constexpr int SHIFT_DOT_THREADS = 1024;
 __global__ __launch_bounds__(SHIFT_DOT_THREADS) void shift_dot_kernel(const double* __restrict__ shifted, const double* __restrict__ w,
                                                                      const double* __restrict__ ksd2, long long N,
                                                                      double* __restrict__ grad, double* __restrict__ loss_out) {
-  __shared__ double red[SHIFT_DOT_THREADS];
+  __shared__ double red[SHIFT_DOT_THREADS / 64];
   const long long p = blockIdx.x;
   const double* qp = shifted + (2 * p) * N;
   const double* qm = qp + N;
@@ -876,11 +876,16 @@ __global__ __launch_bounds__(SHIFT_DOT_THREADS) void shift_dot_kernel(const doub
   } else {
     for (long long z = threadIdx.x; z < N; z += SHIFT_DOT_THREADS) acc += w[z] * (qp[z] - qm[z]);
   }
-  red[threadIdx.x] = acc;
+  // wave shuffles, then the 16 wave sums in fixed order: deterministic
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  for (int s = SHIFT_DOT_THREADS / 2; s > 0; s >>= 1) {      // fixed-order tree: deterministic
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < SHIFT_DOT_THREADS / 64; ++w) tot += red[w];
+    red[0] = tot;
   }
   if (threadIdx.x == 0) {
     double scale = 0.5;

@@ -16,6 +16,7 @@ arithmetic happens:
 S (scores) and K_p are computed once per `train()` call on the GPU.  With a torch.distributed
 process group the 2P shifted circuits are sharded over the ranks (paramshift_shard.py).
 """
+import os
 import time
 from functools import partial
 
@@ -30,6 +31,7 @@ from .quantum_born_machine import QuantumBornMachine
 from .stein_utils import base_hamming_kernel_torch, score_matrix, stein_gram_matrix, tvd_table
 from .utils import calculate_tvd, generate_all_binary_outcomes
 
+_ROCTX = os.environ.get("BORNVI_ROCTX", "0") == "1"
 DENSE_GRAM_MAX_N = 16     # 8 * 4^16 bytes = 32 GiB of the 288 GB HBM; beyond that the matrix-free form
 
 
@@ -41,12 +43,16 @@ class _EventSpan:
         self.timers, self.name = timers, name
 
     def __enter__(self):
+        if _ROCTX:                       # BORNVI_ROCTX=1: named ranges for rocprofv3 --marker-trace / roctx consumers
+            torch.cuda.nvtx.range_push(f"bornvi:{self.name}")
         if self.timers is not None:
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.ev[0].record()
         return self
 
     def __exit__(self, *exc):
+        if _ROCTX:
+            torch.cuda.nvtx.range_pop()
         if self.timers is not None:
             self.ev[1].record()
             self.timers.setdefault(self.name, []).append(self.ev)

@@ -23,6 +23,20 @@ sym() {
   done
 }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
+pmc_sq() {
+  cd /tmp
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
+             "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    rm -rf /root/repo/gpurun_out/pmc_sq_$tag
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d /root/repo/gpurun_out/pmc_sq_$tag -- \
+      python3 /root/repo/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-gate-bench --no-extras --series none > /root/repo/gpurun_out/pmc_sq_$tag.log 2>&1
+    echo "$tag rc=$?"
+    python3 /root/repo/tools/probes/pmc_rows.py "/root/repo/gpurun_out/pmc_sq_$tag/**/*counter_collection.csv" circuit_pass_fast | tail -3
+  done
+  cd /root/repo
+}
 profile() {
   tools/prof_stats.sh r02_n16_L6_dense 2>&1 | tail -14
   tools/prof_stats.sh r02_n20_L8_kron --workload n20_L8_kron 2>&1 | tail -8
