@@ -95,7 +95,7 @@ def test_bench_dist_selftest_two_ranks(dev, tmp_path):
     gradient with an un-sharded recomputation on every rank, then the bench emits its JSON line with per-phase
     milliseconds per rank."""
     argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "n12_L4_dense", "--dist-selftest",
-            "--no-cpu-baseline", "--no-gate-bench", "--no-extras", "--series", "none", "--repeats", "1"]
+            "--no-cpu-baseline", "--no-gate-bench", "--no-extras", "--series", "n8_L4_dense", "--repeats", "1"]
     codes = run_ranks(shard_worker.bench_rank, 2, (argv, str(tmp_path)), timeout=900)
     assert codes == [0, 0], (codes, _errors(tmp_path))
     line = [l for l in open(tmp_path / "bench0.out").read().splitlines() if l.startswith("{")][-1]
@@ -104,4 +104,6 @@ def test_bench_dist_selftest_two_ranks(dev, tmp_path):
     st = rec["dist_selftest"]
     assert st["ok"] and st["ranks"] == 2 and st["max_rel_err_grad"] < 1e-10 and st["max_rel_err_y"] < 1e-12
     assert len(rec["phase_ms_per_rank"]) == 2 and all("circuits" in p and "allgather" in p for p in rec["phase_ms_per_rank"])
+    ser = rec["series"][0]                                # the second workload measured beside the headline, same ranks
+    assert ser["workload"] == "n8_L4_dense" and ser["n_gpus"] == 2 and ser["value"] > 0 and len(ser["phase_ms_per_rank"]) == 2
     assert not [l for l in open(tmp_path / "bench1.out").read().splitlines() if l.startswith("{")]   # rank 0 prints
