@@ -201,8 +201,8 @@ int bornvi_stein_quadform_sym_ld(bornvi_handle h, int n, const double* K, long l
                                  double* ksd2, double* y, void* workspace, size_t workspace_bytes,
                                  bornvi_stream stream);
 
-/* Strip-pair shard of the symmetric form (several GPUs, each reading only its part of the UPPER triangle); n >= 8.
- * The rows are cut into strips ("bands": one workgroup each) of bornvi_stein_sym_strip_rows() = 128 rows; pair p =
+/* Strip-pair shard of the symmetric form (several GPUs, each reading only its part of the UPPER triangle); n >= 9.
+ * The rows are cut into strips ("bands": one workgroup each) of bornvi_stein_sym_strip_rows() = 256 rows; pair p =
  * strips p and n_strips-1-p (a long and a short part of the triangle).  A GPU owning pairs [pair_begin, pair_end) holds K_lo = rows of the strips
  * [pair_begin, pair_end) and K_hi = rows of the strips [n_strips - pair_end, n_strips - pair_begin) (each block
  * built with bornvi_stein_gram_build_rows) and gets y_partial dev [2^n] and ksd2_partial dev [1]: its additive

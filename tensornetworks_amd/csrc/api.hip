@@ -747,7 +747,7 @@ int bornvi_stein_quadform_sym_pairs_ld(bornvi_handle h, int n, const double* K_l
   if (!q || !ksd2_partial || !y_partial) return fail(h, BORNVI_ERR_INVALID, "null pointer");
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
   if (!valid_ld(n, ld)) return fail(h, BORNVI_ERR_INVALID, "leading dimension must be even, >= 2^n and <= 2^n + 4096");
-  if (n < 8) return fail(h, BORNVI_ERR_UNSUPPORTED, "the strip-pair shard needs n >= 8 (bands of 128 rows)");
+  if (n < quadform_sym_min_n()) return fail(h, BORNVI_ERR_UNSUPPORTED, "the strip-pair shard needs at least two bands of rows (n >= 9)");
   const long long N = 1ll << n, R = quadform_sym_rows_per_strip();
   const long long ns = N / R, npairs = (ns + 1) / 2;
   if (pair_begin < 0 || pair_end < pair_begin || pair_end > npairs) return fail(h, BORNVI_ERR_INVALID, "strip-pair range out of bounds");

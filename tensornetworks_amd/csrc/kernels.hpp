@@ -81,6 +81,7 @@ hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_
                                      long long pair_end, const double* q, double* y_or_null, double* ksd2, double* ws,
                                      hipStream_t st);
 int quadform_sym_rows_per_strip();
+int quadform_sym_min_n();     // below it the symmetric entry point runs the full-matrix kernel, and there are no strip pairs
 // matrix-free mat-vec helpers
 hipError_t launch_kron_pack(int n, double length_scale, const double* S, const double* q,
                             double* packed /*complex [(n+2)/2, 2^n]*/, double* gate /*[8]*/, hipStream_t st);

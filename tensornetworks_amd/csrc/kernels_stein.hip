@@ -471,7 +471,7 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 // symmetric quadratic form: K_p is symmetric (gram_kernel evaluates every entry symmetrically, so it
 // is BITWISE symmetric), hence y = K q needs only the upper triangle: half the HBM traffic.
 //
-// Work split.  The rows are cut into BANDS of SYM_BAND = 128 rows; a workgroup of four waves owns a band (paired
+// Work split.  The rows are cut into BANDS of SYM_BAND = 256 rows; a workgroup of eight waves owns a band (paired
 // with its mirror band for balance) and one piece of its columns; wave w of the workgroup owns the 32 rows
 // [i0 + 32 w, i0 + 32 w + 32) of the band and sweeps the columns j >= its first row:
 //   row part     yrow[i] = sum_j K_ij q_j over the wave's columns   (32 accumulators per lane, wave-reduced at the end)
@@ -481,36 +481,40 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 // kernel 8 % (2.85 vs 2.63 ms without them) and made its time depend on where the matrix had been allocated (2.85 ..
 // 3.35 ms: read/write turn-arounds on whichever HBM channels the two buffers share; measured with timing-only builds,
 // tools/probes/sym_probe.py -- neither the row pitch, the TLB reach nor the number of loads in flight mattered).
-// Here the four waves of a band add their column partials through LDS, in fixed order, and ONE 4 KiB store per
-// 512-column trip leaves the workgroup: N^2 / 256 doubles (0.13 GB).  Only the columns next to the diagonal, where
-// the four waves' ranges differ, keep per-wave partials (< 512 doubles per wave).  The second kernel adds, for each
+// Here the eight waves of a band add their column partials through LDS, in fixed order, and ONE 4 KiB store per
+// 512-column trip leaves the workgroup: N^2 / 512 doubles (0.07 GB).  Only the columns next to the diagonal, where
+// the waves' ranges differ, keep per-wave partials (< 512 doubles per wave).  The second kernel adds, for each
 // column j, the row result and every partial above it: no atomics, fixed summation order, deterministic.
 //
-// Layout facts used below: band S covers rows [128 S, 128 S + 128); its BULK are the columns from
-// bulk_start(S) = min(N, 512 (S / 4 + 1)) on -- right of the diagonal blocks of all four waves and a multiple of the
+// Layout facts used below: band S covers rows [256 S, 256 S + 256); its BULK are the columns from
+// bulk_start(S) = min(N, 512 (S / 2 + 1)) on -- right of the diagonal blocks of all its waves and a multiple of the
 // 512-column trip; the NEAR part of wave w are the columns [128-aligned start of its diagonal block, bulk_start).
 // ------------------------------------------------------------------------------------------------
 #ifndef BORNVI_SYM_ABLATE      // timing-only builds (tools/probes): 2 = no column part at all (results invalid)
 #define BORNVI_SYM_ABLATE 0
 #endif
+#ifndef BORNVI_SYM_WAVES
+#define BORNVI_SYM_WAVES 8     // measured on six 32 GiB allocations held at once: 2.66-2.82 ms (8 waves) vs 2.66-2.94 ms (4)
+#endif
 constexpr int SYM_ROWS = 32;                        // rows per wave (its row accumulators)
-constexpr int SYM_WAVES = 4;
+constexpr int SYM_WAVES = BORNVI_SYM_WAVES;         // 4 or 8 waves per band
 constexpr int SYM_BAND = SYM_ROWS * SYM_WAVES;      // rows per workgroup: the unit of the strip-pair shard
+constexpr int SYM_BP = 512 / SYM_BAND;              // bands per 512-column trip width
 constexpr int SYM_NEAR = 512;                       // per-wave capacity of near-diagonal column partials (< 480 used)
 constexpr int SYM_MAX_PARTS = 16;                   // column pieces per band (row-partial buffers in the workspace)
-constexpr int SYM_MIN_N = 8;                        // smaller matrices (< 256 rows) go through the full-matrix kernel
+constexpr int SYM_MIN_N = (SYM_WAVES == 4) ? 8 : 9; // smaller matrices (< 2 bands) go through the full-matrix kernel
 typedef double sym_d2 __attribute__((ext_vector_type(2)));
 typedef unsigned int sym_u4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline long long sym_bulk_start(long long S, long long N) {
-  const long long b = 512 * (S / 4 + 1);
+  const long long b = 512 * (S / SYM_BP + 1);
   return b < N ? b : N;
 }
 // offset (doubles) of band S's bulk partials Z2_S[j - bulk_start(S)], j in [bulk_start(S), N): bands in order
 __host__ __device__ inline long long sym_z2_offset(long long S, long long N) {
   if (N <= 512) return 0;
-  const long long m = S / 4, r = S % 4;
-  return 4 * m * N - 1024 * m * (m + 1) + r * (N - 512 * (m + 1));
+  const long long m = S / SYM_BP, r = S % SYM_BP;
+  return SYM_BP * m * N - 256 * SYM_BP * m * (m + 1) + r * (N - 512 * (m + 1));
 }
 
 // 16 bytes through the wave's buffer descriptor (its 32 rows): address = base + voff (per lane) + soff (wave-uniform:
@@ -555,8 +559,8 @@ __device__ __forceinline__ void sym_trip(__amdgpu_buffer_rsrc_t rsrc, long long 
   }
 }
 
-// One band for one workgroup: wave `wave` owns rows [128 S + 32 wave, + 32).  part 0 also sweeps the NEAR columns.
-// All four waves run the same number of bulk trips (one workgroup barrier each).
+// One band for one workgroup: wave `wave` owns rows [SYM_BAND S + 32 wave, + 32).  part 0 also sweeps the NEAR columns.
+// All waves run the same number of bulk trips (one workgroup barrier each).
 __device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb /* first row of the band */, long long ld,
                                                   const double* __restrict__ q, double* __restrict__ yrow,
                                                   double* __restrict__ Z1, double* __restrict__ Z2, long long N, long long S,
@@ -603,9 +607,16 @@ __device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb 
       for (int c = 0; c < 4; ++c) zbuf[buf][wave][c * 64 + lane] = (sym_d2){z[c][0], z[c][1]};
       __syncthreads();
       const int tid = wave * 64 + lane;                 // columns cb + 2 tid, cb + 2 tid + 1
-      const sym_d2 a0 = zbuf[buf][0][tid], a1 = zbuf[buf][1][tid], a2 = zbuf[buf][2][tid], a3 = zbuf[buf][3][tid];
-      const sym_d2 sum = (a0 + a1) + (a2 + a3);
-      *reinterpret_cast<double2*>(Z2s + cb + 2 * tid) = make_double2(sum.x, sum.y);
+      if (SYM_WAVES == 4) {
+        const sym_d2 sum = (zbuf[buf][0][tid] + zbuf[buf][1][tid]) + (zbuf[buf][2][tid] + zbuf[buf][3][tid]);
+        *reinterpret_cast<double2*>(Z2s + cb + 2 * tid) = make_double2(sum.x, sum.y);
+      } else {                                          // 512 threads, one column each
+        const double* zb = reinterpret_cast<const double*>(&zbuf[buf][0][0]);
+        double sum = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < SYM_WAVES; w2 += 2) sum += zb[w2 * 512 + tid] + zb[(w2 + 1) * 512 + tid];
+        Z2s[cb + tid] = sum;
+      }
     }
   }
   __syncthreads();      // the LDS buffers are reused by the next band of this workgroup
@@ -625,7 +636,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES, 2) void quadform_sym_kernel(const d
                                                                        const double* __restrict__ q, double* __restrict__ yrow,
                                                                        double* __restrict__ Z1, double* __restrict__ Z2,
                                                                        long long N, int nparts_log2) {
-  __shared__ sym_d2 zbuf[2][SYM_WAVES][256];           // 2 x 4 x 4 KiB: the waves' column partials of a trip
+  __shared__ sym_d2 zbuf[2][SYM_WAVES][256];           // 2 x SYM_WAVES x 4 KiB: the waves' column partials of a trip
   const int lane = threadIdx.x & 63;
   // readfirstlane makes the wave index provably uniform, so q_i and all row offsets live in scalar registers
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -660,7 +671,7 @@ __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* 
   const long long j = (long long)blockIdx.x * 64 + lane;
   double acc = 0.0;
   if (j < N) {
-    const long long smax = 4 * (j / 512);           // bands whose bulk starts at or left of column j
+    const long long smax = SYM_BP * (j / 512);      // bands whose bulk starts at or left of column j
 #pragma unroll 1
     for (int rg = 0; rg < 2; ++rg) {
       const long long r0 = rg ? hi0 : lo0;
@@ -725,7 +736,7 @@ hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_
   const long long npairs = pair_end - pair_begin;
   int parts_log2 = 0;                                       // enough column pieces for two workgroups per CU
   static const int min_wgs = [] { const char* e = getenv("BORNVI_SYM_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
-  while ((1 << parts_log2) < SYM_MAX_PARTS && (npairs << parts_log2) < min_wgs) ++parts_log2;
+  while ((1 << parts_log2) < SYM_MAX_PARTS && (npairs << parts_log2) < min_wgs * 4 / SYM_WAVES) ++parts_log2;
   const int nparts = 1 << parts_log2;
   if (npairs > 0) {
     quadform_sym_kernel<<<(unsigned)(npairs << parts_log2), 64 * SYM_WAVES, 0, st>>>(K_lo, K_hi, ld, pair_begin, pair_end, q, yrow,
@@ -755,6 +766,7 @@ hipError_t launch_quadform_sym(int n, const double* K, long long ld, const doubl
 }
 
 int quadform_sym_rows_per_strip() { return SYM_BAND; }
+int quadform_sym_min_n() { return SYM_MIN_N; }
 
 // ------------------------------------------------------------------------------------------------
 // matrix-free y = K_p q.  The n+1 real vectors v_0 = q, v_{b+1} = s_b o q

@@ -119,7 +119,7 @@ def test_symmetric_quadform_equals_full(be, dev, n):
     assert abs(k_full.item() - k_sym.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
     # the reference value: dense NumPy product
     np.testing.assert_allclose(y_sym.cpu().numpy(), K.cpu().numpy() @ q.cpu().numpy(), rtol=0, atol=1e-13 * scale)
-    if n >= 8:
+    if n >= 9:
         # a padded row pitch (the [:, :2^n] view of a [2^n, 2^n + 32] buffer) holds the same matrix and contracts to the
         # same bits; deterministic from call to call
         Kp = be.stein_gram(S, n, 1.0, ld=2 ** n + 32)
@@ -130,7 +130,7 @@ def test_symmetric_quadform_equals_full(be, dev, n):
         assert torch.equal(y_again, y_sym) and torch.equal(k_again, k_sym)
 
 
-@pytest.mark.parametrize("n,world", [(8, 1), (9, 2), (10, 2), (10, 3), (12, 8), (13, 4), (14, 8)])
+@pytest.mark.parametrize("n,world", [(9, 1), (9, 2), (10, 2), (10, 3), (12, 8), (13, 4), (14, 8)])
 def test_sym_strip_pair_shard_sums_to_full(be, dev, n, world):
     """Several GPUs: each rank holds two row blocks of K_p (its strip pairs of the upper triangle) and computes
     an additive share of (K q, q^T K q); the shares (what the all-reduce sums) add up to the full contraction."""
@@ -157,7 +157,7 @@ def test_sym_strip_pair_shard_sums_to_full(be, dev, n, world):
     scale = (K.abs() @ q).max().item()
     assert (total[:-1] - y_ref).abs().max().item() <= 1e-13 * scale
     assert abs(total[-1].item() - k_ref.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
-    assert be.sym_pair_shard(7, 0, 2) is None       # 128 outcomes: one band of 128 rows, no pairs to deal out
+    assert be.sym_pair_shard(8, 0, 2) is None       # 256 outcomes: one band of 256 rows, no pairs to deal out
 
 
 def test_length_scale(be, dev):
