@@ -23,6 +23,8 @@ sym() {
   done
 }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
+rehearse() { for N in 2 4; do N=$N tools/rehearse_multi.sh; done; }
+emulate() { run 900 r2_emulate_ranks.log python tools/probes/emulate_ranks.py; grep "^n=" gpurun_out/r2_emulate_ranks.log; }
 pmc_sq() {
   cd /tmp
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
