@@ -271,6 +271,11 @@ int bornvi_adjoint_vjp(bornvi_handle h, int ansatz, int n, int layers, const dou
                        const double* dLdq, double* grad, void* workspace, size_t workspace_bytes,
                        bornvi_stream stream);
 
+/* Diagnostic builds only (-DBORNVI_STAMPS=1, tools/probes): totals of the shader cycles wave 0 of every workgroup of the
+ * fast circuit kernel spent per phase of its tile trips since the last call (out16[0..7]; out16[8] = workgroups counted);
+ * synchronises the device.  All zeros in the production build. */
+int bornvi_debug_circuit_stamps(bornvi_handle h, unsigned long long* out16);
+
 /* ---- introspection (host only, no GPU needed): serialised execution plan of a circuit ------
  * (passes / stages / fused gates) as uint32 words; used by the CPU tests to check the
  * planner against the oracle.  Returns the number of words (writes min(cap, words)). */

@@ -93,6 +93,7 @@ _PROTOS = {
                                        C.c_size_t, C.c_void_p]),
     "bornvi_adjoint_vjp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_debug_circuit_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "bornvi_plan_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t]),
     "bornvi_stream_create_cu_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bornvi_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -910,6 +910,14 @@ int bornvi_adjoint_vjp(bornvi_handle h, int ansatz, int n, int layers, const dou
   return BORNVI_OK;
 }
 
+int bornvi_debug_circuit_stamps(bornvi_handle h, unsigned long long* out16) {
+  if (!h || !out16) return BORNVI_ERR_INVALID;
+  DEVICE_SCOPE(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, read_circuit_stamps(out16));
+  return BORNVI_OK;
+}
+
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
   PlanOptions opt;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }

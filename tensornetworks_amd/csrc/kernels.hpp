@@ -21,6 +21,7 @@ hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* th
                               int shift_mode, int p_begin, int p_stride, int include_base, long long b_offset, int batch,
                               double* gates, const int* shift_tab, hipStream_t st);
 hipError_t prepare_circuit_kernel(size_t lds_bytes);
+hipError_t read_circuit_stamps(unsigned long long* out16);   // diagnostic builds (BORNVI_STAMPS) only: zeros otherwise
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,
                                const void* in, void* out, double* probs, const double* gates,
                                long long gate_stride, int max_workgroups, int dbg, hipStream_t st);

@@ -430,6 +430,48 @@ __device__ __forceinline__ void load_u(const double2* __restrict__ Um, double (&
   U[0] = u00.x; U[1] = u00.y; U[2] = u01.x; U[3] = u01.y; U[4] = u10.x; U[5] = u10.y; U[6] = u11.x; U[7] = u11.y;
 }
 
+// The same gate with the matrix in SCALAR registers (experiment BORNVI_U_SGPR, tools/probes): every instruction reads
+// exactly one matrix element, i.e. one SGPR pair -- inside the constant-bus limit of a VOP3 instruction.
+__device__ __forceinline__ void gate_pair_inplace_s(double& x0r, double& x0i, double& x1r, double& x1i,
+                                                    const double (&U)[8]) {
+  double t0, t1, t2, t3;
+  asm("v_mul_f64 %4, %9, %1\n\t"
+      "v_mul_f64 %5, %9, %0\n\t"
+      "v_mul_f64 %6, %13, %1\n\t"
+      "v_mul_f64 %7, %13, %0\n\t"
+      "v_fma_f64 %4, %10, %2, -%4\n\t"
+      "v_fma_f64 %5, %10, %3, %5\n\t"
+      "v_fma_f64 %6, %12, %0, -%6\n\t"
+      "v_fma_f64 %7, %12, %1, %7\n\t"
+      "v_fma_f64 %4, -%11, %3, %4\n\t"
+      "v_fma_f64 %5, %11, %2, %5\n\t"
+      "v_fma_f64 %6, -%15, %3, %6\n\t"
+      "v_fma_f64 %7, %15, %2, %7\n\t"
+      "v_fma_f64 %0, %8, %0, %4\n\t"
+      "v_fma_f64 %1, %8, %1, %5\n\t"
+      "v_fma_f64 %2, %14, %2, %6\n\t"
+      "v_fma_f64 %3, %14, %3, %7"
+      : "+v"(x0r), "+v"(x0i), "+v"(x1r), "+v"(x1i), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "s"(U[0]), "s"(U[1]), "s"(U[2]), "s"(U[3]), "s"(U[4]), "s"(U[5]), "s"(U[6]), "s"(U[7]));
+}
+
+__device__ __forceinline__ double uniform_to_sgpr(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int I>
+__device__ __forceinline__ void op_u1_inplace_s(double (&ar)[16], double (&ai)[16], const double (&U)[8]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j & (1 << I)) continue;
+    gate_pair_inplace_s(ar[j], ai[j], ar[j | (1 << I)], ai[j | (1 << I)], U);
+  }
+}
+
+#ifndef BORNVI_U_SGPR
+#define BORNVI_U_SGPR 0
+#endif
+
 template <int I>
 __device__ __forceinline__ void op_u1_inplace(double (&ar)[16], double (&ai)[16], const double (&U)[8]) {
 #pragma unroll
@@ -501,10 +543,25 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
   if (PRE) apply_sign_bits(my_sg & 0xffffu, ar, ai);
   if (!(DEBUG && (dbg & 1))) {
     double U[8];
+#if BORNVI_U_SGPR
+    // the wave-uniform matrix goes from LDS through a VGPR staging set into scalar registers; the next gate's LDS reads
+    // are issued into the freed staging set before this gate's FMAs (their latency hides under them)
+    double S_[8];
+    if (NG > 0) load_u(Us, U);
+#define BORNVI_GATE_S(I_)                                                            \
+    if (NG > I_) {                                                                   \
+      _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) S_[e_] = uniform_to_sgpr(U[e_]); \
+      if (NG > I_ + 1) load_u(Us + 4 * (I_ + 1), U);                                 \
+      op_u1_inplace_s<I_>(ar, ai, S_);                                               \
+    }
+    BORNVI_GATE_S(0) BORNVI_GATE_S(1) BORNVI_GATE_S(2) BORNVI_GATE_S(3)
+#undef BORNVI_GATE_S
+#else
     if (NG > 0) { load_u(Us, U); op_u1_inplace<0>(ar, ai, U); }
     if (NG > 1) { load_u(Us + 4, U); op_u1_inplace<1>(ar, ai, U); }
     if (NG > 2) { load_u(Us + 8, U); op_u1_inplace<2>(ar, ai, U); }
     if (NG > 3) { load_u(Us + 12, U); op_u1_inplace<3>(ar, ai, U); }
+#endif
   }
   if (POST) apply_sign_bits(my_sg >> 16, ar, ai);
   if (IO == 2) {
@@ -558,7 +615,28 @@ __device__ __forceinline__ void stage_dispatch(uint32_t kind, double2* __restric
 #undef BORNVI_STAGE
 }
 
-template <bool DEBUG>
+// In-kernel phase stamps (diagnostic build only, -DBORNVI_STAMPS=1, tools/probes/stamp_probe.py): wave 0 of every
+// workgroup adds up, per phase of a tile trip, the shader cycles (s_memtime) it spent there; totals go to a buffer that
+// nothing else reads.  In the production build every BORNVI_STAMP expands to nothing.
+#ifndef BORNVI_STAMPS
+#define BORNVI_STAMPS 0
+#endif
+#ifndef BORNVI_SPLIT_PREFETCH
+#define BORNVI_SPLIT_PREFETCH 1      // 0: never use the SPLIT instantiation (A/B against the round-1 form)
+#endif
+#if BORNVI_STAMPS
+__device__ unsigned long long g_stamp_totals[16];
+#define BORNVI_STAMP(PH_)                                                        \
+  do {                                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter();                \
+    stamp_acc[PH_] += now_ - stamp_last;                                         \
+    stamp_last = now_;                                                           \
+  } while (0)
+#else
+#define BORNVI_STAMP(PH_) do { } while (0)
+#endif
+
+template <bool DEBUG, bool SPLIT>
 __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const uint32_t* __restrict__ fast, uint32_t fast_off,
     const double2* __restrict__ in, double2* __restrict__ out, double* __restrict__ probs,
@@ -685,6 +763,10 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
   // the loads of the next one and works on its own.  With a second load site (a prologue) the compiler has to merge
   // two definitions of the in-flight registers at the loop header and may do it with register copies placed right
   // behind a load -- copies of registers whose data has not arrived (tools/check_async_regs.py looks for that).
+#if BORNVI_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_last = __builtin_readcyclecounter();
+#endif
   uint32_t g_tab = 0xffffffffu;   // tile row whose stage tables are in LDS
   uint32_t parity = 1;            // matrix buffer of the current tile (trip -1 stages tile 0's matrices into buffer 0)
   const uint32_t* __restrict__ FS0 = F + FH_WORDS;
@@ -715,11 +797,13 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       pdst = row < 0 ? share.trash : probs + ((long long)row << n);
     }
     void* hbm_base = fin ? (void*)pdst : (void*)dst;
+    BORNVI_STAMP(real ? 6 : 7);     // loop overhead / the pipeline-start trip
     if (real) {
       // ---- the tile has arrived in registers: all but this wave's 16 tile-out stores are done (after trip -1
       // nothing is outstanding) ----
       if (DEBUG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      BORNVI_STAMP(0);              // waiting for the prefetched tile
 #pragma unroll
       for (int i = 0; i < MAX_TILE_ITERS; ++i) asm volatile("" : "+v"(v[i]));
       // ---- registers -> LDS: the tile (head CNOTs of the pass folded into the slot), unless the first stage
@@ -737,8 +821,73 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       if (direct_in) BORNVI_RUN_STAGE(0, 1);    // (the matrices were staged a trip ago)
       asm volatile("" ::: "memory");
     }
+    BORNVI_STAMP(1);                // tile -> LDS (or the direct first stage)
+    if (SPLIT) {
+    // ---- the registers are free: the next tile starts its trip from HBM.  Large tiles (one workgroup of >= 4 waves per
+    // CU, all in step between barriers): the 16 loads are issued in two halves BETWEEN the stages, and the two halves of
+    // the workgroup's waves (SIMD partners: wave w and w + nwaves/2 share a SIMD) issue theirs in alternate stages.  A
+    // wave-level 1-KiB load takes ~100 cycles of the CU's memory pipe, so 16 of them issued back to back by all waves at
+    // once blocked every wave for 11 % of a trip at n = 20 with the VALU idle (in-kernel stamps,
+    // tools/probes/stamp_probe.py); now one partner computes while the other issues: -4 % at n = 20, L = 8, rows
+    // bit-identical.  2^11 tiles (four independent workgroups per CU already interleave their phases; measured
+    // neutral to +2 %) issue all 16 before the first stage as before.  Either way there is ONE load site per in-flight
+    // register (inside the loop below, which always runs at least once) and all loads precede the trip's 16 stores:
+    // the hand-counted vmcnt waits are unchanged.
+    uint32_t gn_h = 0;
+    long long bn_h = 0;
+    if (has_next) {
+      gn_h = (uint32_t)(Tnext & ((1ll << gbits) - 1));
+      bn_h = Tnext >> gbits;
+      uint32_t tt_ = t;
+      asm volatile("" : "+v"(tt_));
+      if (direct_in && gn_h != g_pref) {   /* rare: compiler-tracked load, waited for inside this branch */
+        g_pref = gn_h;
+        tw_in[tt_] = fast[in_tab + (gn_h << kt) + tt_];
+      }
+      if (tt_ < npieces) async_load16(mp, tw_mat[tt_], gates + bn_h * gate_stride);
+    }
+    const bool want_v = has_next && !init && !(dbg & 4);
+    BORNVI_STAMP(2);                // head of the prefetch (matrix piece)
+    {
+      const int s0 = (real && direct_in) ? 1 : 0;
+      const int ns = real ? nstages : 0;
+      const int niter = (ns - s0 > 0) ? ns - s0 : 1;
+#ifndef BORNVI_SPLIT_STAGGER
+#define BORNVI_SPLIT_STAGGER 1
+#endif
+      const int wc = (BORNVI_SPLIT_STAGGER && 2u * (t >> 6) >= (T >> 6)) ? 1 : 0;     // second half of the workgroup's waves
+      for (int j = 0; j < niter; ++j) {
+        const int s = s0 + j;
+        const bool last = j == niter - 1;
+#define BORNVI_PREFETCH_HALF(C_)                                                                      \
+        if (want_v && (j == wc + 2 * (C_) || (last && wc + 2 * (C_) > j))) {                          \
+          uint32_t tt_ = t;                                                                          \
+          asm volatile("" : "+v"(tt_));                                                              \
+          const uint32_t base_ = tw_in[tt_];                                                         \
+          const double2* src_ = in + (bn_h >= share.fresh_begin ? 0ll : bn_h) * state_stride +       \
+                                (direct_in ? 0u : deposit16(gn_h, 0, gbits, in_gphys));             \
+          _Pragma("unroll") for (int i = 8 * (C_); i < 8 * (C_) + 8; ++i)                            \
+            async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^  \
+                                        ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
+        }
+        BORNVI_PREFETCH_HALF(0)
+        BORNVI_PREFETCH_HALF(1)
+#undef BORNVI_PREFETCH_HALF
+        if (j == 0 && real) __syncthreads();    // the tile (or the first stage's result) is in LDS
+        if (s < ns) {
+          if (s == ns - 1 && direct_out) {
+            BORNVI_RUN_STAGE(s, 2);
+          } else {
+            BORNVI_RUN_STAGE(s, 0);
+            __syncthreads();
+          }
+        }
+      }
+    }
+    } else {
     // ---- the registers are free: the next tile starts its trip from HBM now (the only load site) ----
     if (has_next) BORNVI_PREFETCH(Tnext);
+    BORNVI_STAMP(2);                // issuing the prefetch
     if (real) {
       __syncthreads();                          // the tile (or the first stage's result) is in LDS
       for (int s = direct_in ? 1 : 0; s < nstages; ++s) {
@@ -749,6 +898,10 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
           __syncthreads();
         }
       }
+    }
+    }
+    if (real) {
+      BORNVI_STAMP(3);              // the stages (LDS round trips, gates, barriers)
       // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
       // vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
       if (!direct_out) {
@@ -766,6 +919,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
         }
       }
     }
+    BORNVI_STAMP(4);                // tile out (LDS reads + store issue)
     if (!has_next) break;
     // ---- stage tables of the NEXT tile's row -> LDS.  The launcher makes the grid a multiple of the tiles per
     // state whenever it can, so a workgroup keeps its row and this runs once, in trip -1, beside the first prefetch
@@ -793,7 +947,14 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     asm volatile("" : "+v"(mp));
     if (t < npieces) mats_next[t] = make_double2(mp.x, mp.y);
     __syncthreads();   // the tile is overwritten by the next trip; its matrices are in place
+    BORNVI_STAMP(5);                // end of trip: wait for the matrices in flight, stage them, barrier
   }
+#if BORNVI_STAMPS
+  if (threadIdx.x == 0) {
+    for (int ph = 0; ph < 8; ++ph) atomicAdd(&g_stamp_totals[ph], stamp_acc[ph]);
+    atomicAdd(&g_stamp_totals[8], 1ull);
+  }
+#endif
 #undef BORNVI_RUN_STAGE
 #undef BORNVI_PREFETCH
 }
@@ -959,8 +1120,13 @@ hipError_t prepare_circuit_kernel(size_t lds_bytes) {
                         reinterpret_cast<const void*>(circuit_pass_kernel<false, false>),
                         reinterpret_cast<const void*>(circuit_pass_kernel<true, true>),
                         reinterpret_cast<const void*>(circuit_pass_kernel<false, true>),
-                        reinterpret_cast<const void*>(circuit_pass_fast_kernel<false>),
-                        reinterpret_cast<const void*>(circuit_pass_fast_kernel<true>)};
+                        reinterpret_cast<const void*>(circuit_pass_fast_kernel<false, false>),
+                        reinterpret_cast<const void*>(circuit_pass_fast_kernel<true, false>)};
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_fast_kernel<false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -970,7 +1136,10 @@ hipError_t prepare_circuit_kernel(size_t lds_bytes) {
 
 int circuit_fast_workgroups_per_cu(int threads, size_t lds) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_fast_kernel<false>, threads, lds) != hipSuccess) return 0;
+  const hipError_t e = (BORNVI_SPLIT_PREFETCH && threads >= 256)
+                           ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_fast_kernel<false, true>, threads, lds)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_fast_kernel<false, false>, threads, lds);
+  if (e != hipSuccess) return 0;
   return nb;
 }
 
@@ -987,15 +1156,29 @@ hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, con
   if (wgs > per_state) wgs -= wgs % per_state;
   dim3 grid((unsigned)wgs);
   const dim3 block(1u << (k - 4));
-  if (!dbg)
-    circuit_pass_fast_kernel<false><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
-                                                            probs, gates, gate_stride, 1ll << n, total_tiles,
-                                                            (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, 0, share);
-  else
-    circuit_pass_fast_kernel<true><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out,
-                                                           probs, gates, gate_stride, 1ll << n, total_tiles,
-                                                           (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, dbg, share);
+#define BORNVI_LAUNCH_FAST(D_, S_, DBG_)                                                                                 \
+  circuit_pass_fast_kernel<D_, S_><<<grid, block, lds, st>>>(plan, pass_off, fast, fast_off, (const double2*)in, (double2*)out, \
+                                                             probs, gates, gate_stride, 1ll << n, total_tiles,            \
+                                                             (uint32_t)(lds_tab_off / 16), (uint32_t)(lds_mats2_off / 16), direct_mask, DBG_, share)
+  // large tiles (one workgroup of >= 4 waves per CU): the instantiation that spreads the prefetch over the stages
+  if (dbg) BORNVI_LAUNCH_FAST(true, false, dbg);
+  else if (BORNVI_SPLIT_PREFETCH && block.x >= 256) BORNVI_LAUNCH_FAST(false, true, 0);
+  else BORNVI_LAUNCH_FAST(false, false, 0);
+#undef BORNVI_LAUNCH_FAST
   return hipGetLastError();
+}
+
+// diagnostic builds: read (and clear) the phase-stamp totals; zeros in the production build
+hipError_t read_circuit_stamps(unsigned long long* out16) {
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+#if BORNVI_STAMPS
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_totals), 16 * sizeof(unsigned long long));
+  if (e != hipSuccess) return e;
+  unsigned long long zero[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_totals), zero, sizeof(zero));
+#else
+  return hipSuccess;
+#endif
 }
 
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,

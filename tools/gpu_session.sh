@@ -23,6 +23,15 @@ sym() {
   done
 }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
+circ_ab() {
+  run 300 r2_circ_ab_default.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_default.log
+  for lib in tools/_variants/libbornvi_circ_*.so; do
+    v=$(basename $lib .so)
+    BORNVI_LIB=$PWD/$lib run 300 r2_circ_ab_$v.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_$v.log
+  done
+}
+stamps() { for v in ${STAMP_LIBS:-stamps}; do BORNVI_LIB=$PWD/tools/_variants/libbornvi_circ_$v.so run 300 r2_stamp_probe_$v.log python tools/probes/stamp_probe.py; echo "--- $v"; grep -v amdgpu.ids gpurun_out/r2_stamp_probe_$v.log; done; }
+tests_circ_variant() { BORNVI_LIB=$PWD/tools/_variants/libbornvi_circ_${CIRC_VARIANT}.so run 600 r2_gpu_tests_circ_${CIRC_VARIANT}.log python -m pytest tests/test_gpu_circuit.py -m gpu -x -q; tail -n 4 gpurun_out/r2_gpu_tests_circ_${CIRC_VARIANT}.log; }
 rehearse() { for N in 2 4; do N=$N tools/rehearse_multi.sh; done; }
 emulate() { run 900 r2_emulate_ranks.log python tools/probes/emulate_ranks.py; grep "^n=" gpurun_out/r2_emulate_ranks.log; }
 pmc_sq() {
