@@ -493,6 +493,43 @@ __device__ __forceinline__ void apply_sign_bits(uint32_t m, double (&ar)[16], do
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
+// The LAST gate of an LDS -> LDS stage with the write-back folded in: as soon as a pair has gone through the gate (and
+// the post sign) its two amplitudes are final and go to LDS, while the next pair is still in the FMAs.  All waves of
+// a large-tile workgroup reach the end of a stage together; 16 ds_write_b128 per wave issued in one burst by all of
+// them kept the LDS write path (~80 B/clk/CU) busy for ~1600 cycles per stage with the VALU idle.  Same operations on
+// the same values: bit-identical results.
+#ifndef BORNVI_EARLY_WRITE
+#define BORNVI_EARLY_WRITE 1     // large-tile instantiation only (LT below); 0: round-1 stage body everywhere (A/B)
+#endif
+#ifndef BORNVI_EARLY_STORE
+#define BORNVI_EARLY_STORE 1     // the same for a direct last stage's HBM stores
+#endif
+#ifndef BORNVI_U_PREFETCH
+#define BORNVI_U_PREFETCH 1      // with BORNVI_EARLY_WRITE: two matrix register sets, matrix reads ahead of the amplitude reads
+#endif
+template <int I, bool POST>
+__device__ __forceinline__ void op_u1_last_and_write(double (&ar)[16], double (&ai)[16], const double (&U)[8], uint32_t post_bits,
+                                                     double2* __restrict__ tile, uint32_t wa0, const uint32_t (&G)[10]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j & (1 << I)) continue;
+    const int j1 = j | (1 << I);
+    gate_pair_inplace(ar[j], ai[j], ar[j1], ai[j1], U);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int jj = q ? j1 : j;
+      double xr = ar[jj], xi = ai[jj];
+      if (POST) {
+        const int sw = (int)((post_bits << (31 - jj)) & 0x80000000u);
+        xr = __hiloint2double(__double2hiint(xr) ^ sw, __double2loint(xr));
+        xi = __hiloint2double(__double2hiint(xi) ^ sw, __double2loint(xi));
+      }
+      const uint32_t wa = wa0 ^ (((jj & 1) ? G[FS_WB] : 0u) ^ ((jj & 2) ? G[FS_WB + 1] : 0u) ^ ((jj & 4) ? G[FS_WB + 2] : 0u) ^ ((jj & 8) ? G[FS_WB + 3] : 0u));
+      *reinterpret_cast<double2*>(reinterpret_cast<char*>(tile) + wa) = make_double2(xr, xi);
+    }
+  }
+}
+
 // Vector memory ops the COMPILER does not track (it would otherwise drain vmcnt to 0 at every loop merge, i.e.
 // wait for the previous tile's stores and for the next tile's loads in the middle of the pipeline).  The kernel
 // waits by hand: s_waitcnt vmcnt(N) = all but the wave's N youngest vector-memory ops are done, loads and
@@ -513,17 +550,57 @@ __device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void
   asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
 }
 
+// The same for a direct last stage (IO == 2): the pair's two results go straight to HBM behind its gate -- the 16
+// stores of the tile are spread over the last gate instead of one burst per wave (a 1-KiB store takes ~100 cycles of the
+// CU's memory pipe).  Still exactly 16 stores per wave and tile, all behind the trip's loads.
+template <int I, bool POST>
+__device__ __forceinline__ void op_u1_last_and_store(double (&ar)[16], double (&ai)[16], const double (&U)[8], uint32_t post_bits,
+                                                     uint32_t ha0, const uint32_t (&hbm_basis)[4], void* hbm_base, bool fin) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j & (1 << I)) continue;
+    const int j1 = j | (1 << I);
+    gate_pair_inplace(ar[j], ai[j], ar[j1], ai[j1], U);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int jj = q ? j1 : j;
+      double xr = ar[jj], xi = ai[jj];
+      if (POST) {
+        const int sw = (int)((post_bits << (31 - jj)) & 0x80000000u);
+        xr = __hiloint2double(__double2hiint(xr) ^ sw, __double2loint(xr));
+        xi = __hiloint2double(__double2hiint(xi) ^ sw, __double2loint(xi));
+      }
+      const uint32_t ha = ha0 ^ (((jj & 1) ? hbm_basis[0] : 0u) ^ ((jj & 2) ? hbm_basis[1] : 0u) ^ ((jj & 4) ? hbm_basis[2] : 0u) ^ ((jj & 8) ? hbm_basis[3] : 0u));
+      if (fin) async_store8(ha, xr * xr + xi * xi, hbm_base);
+      else async_store16(ha, (d2_t){xr, xi}, hbm_base);
+    }
+  }
+}
+
 // One stage on the 16 amplitudes a thread owns, specialised on the number of fused gates (the planner puts
 // them on register bits 0 .. NG-1) and on the two CZ sign products: straight-line code, no merges of the
 // 64 amplitude registers (conditional gates cost ~100 register copies per stage in the generic kernel).
 // IO: 0 = LDS -> LDS;  1 = the amplitudes are the prefetched registers `v` (first stage of a pass: no tile
 // fill, no LDS read);  2 = the results go straight to HBM (last stage: no LDS write, no tile drain): 16 stores
 // at  hbm_off ^ (xor of hbm_basis over the bits of the slot number), |amp|^2 as 8 bytes when `fin`.
-template <int NG, bool PRE, bool POST, int IO, bool DEBUG>
+// LT: large-tile instantiation (one workgroup of >= 4 waves per CU, all waves in step between barriers): the stage
+// body folds the write-back into the last gate and keeps the next gate's matrix in flight.  Measured at n = 20, L = 8:
+// -2.4 % (early write-back) and -5.2 % (both) on top of the split prefetch; at 2^11 tiles (four independent
+// workgroups per CU) neutral within noise, so those keep the round-1 body.  Same operations: bit-identical rows.
+template <int NG, bool PRE, bool POST, int IO, bool DEBUG, bool LT>
 __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const double2* __restrict__ Us, uint32_t my_rw,
                                            uint32_t my_sg, const uint32_t (&G)[10], int dbg, d2_t (&v)[16],
                                            uint32_t hbm_off, const uint32_t (&hbm_basis)[4], void* hbm_base, bool fin) {
   double ar[16], ai[16];
+#if BORNVI_U_PREFETCH
+  // (first: LDS returns in order, so the first gate can start as soon as ITS amplitudes have arrived behind the matrix)
+  double Ua[8], Ub[8];
+  constexpr bool EARLY = BORNVI_EARLY_WRITE && LT && !DEBUG && NG > 0 && (IO != 2 || BORNVI_EARLY_STORE);
+  if (EARLY) {
+    load_u(Us, Ua);
+    if (NG > 1) load_u(Us + 4, Ub);
+  }
+#endif
   if (IO == 1) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) { ar[j] = v[j].x; ai[j] = v[j].y; }
@@ -541,6 +618,40 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
     }
   }
   if (PRE) apply_sign_bits(my_sg & 0xffffu, ar, ai);
+  if (BORNVI_EARLY_WRITE && LT && !DEBUG && NG > 0 && (IO != 2 || BORNVI_EARLY_STORE)) {
+    constexpr int LAST = NG > 0 ? NG - 1 : 0;
+    uint32_t wa0 = (IO == 2) ? hbm_off : (my_rw >> 16) << 4;
+    // the last gate with its write-back: to LDS, or (direct last stage) to HBM
+#define BORNVI_LAST_GATE(U_)                                                                                   \
+    do {                                                                                                       \
+      asm volatile("" : "+v"(wa0));   /* the write base is formed here, before the last gate */                \
+      if (IO == 2) op_u1_last_and_store<LAST, POST>(ar, ai, U_, my_sg >> 16, wa0, hbm_basis, hbm_base, fin);   \
+      else op_u1_last_and_write<LAST, POST>(ar, ai, U_, my_sg >> 16, tile, wa0, G);                            \
+    } while (0)
+#if BORNVI_U_PREFETCH
+    // two matrix register sets: the next gate's four broadcast LDS reads are in flight under the current gate's FMAs
+    // (the early write-back freed the registers for the second set)
+    if (NG == 1) { BORNVI_LAST_GATE(Ua); return; }
+    op_u1_inplace<0>(ar, ai, Ua);
+    if (NG > 2) load_u(Us + 8, Ua);
+    if (NG == 2) { BORNVI_LAST_GATE(Ub); return; }
+    op_u1_inplace<1>(ar, ai, Ub);
+    if (NG > 3) load_u(Us + 12, Ub);
+    if (NG == 3) { BORNVI_LAST_GATE(Ua); return; }
+    op_u1_inplace<2>(ar, ai, Ua);
+    BORNVI_LAST_GATE(Ub);
+    return;
+#else
+    double U[8];
+    if (NG > 1) { load_u(Us, U); op_u1_inplace<0>(ar, ai, U); }
+    if (NG > 2) { load_u(Us + 4, U); op_u1_inplace<1>(ar, ai, U); }
+    if (NG > 3) { load_u(Us + 8, U); op_u1_inplace<2>(ar, ai, U); }
+    load_u(Us + 4 * LAST, U);
+    BORNVI_LAST_GATE(U);
+    return;
+#endif
+#undef BORNVI_LAST_GATE
+  }
   if (!(DEBUG && (dbg & 1))) {
     double U[8];
 #if BORNVI_U_SGPR
@@ -592,14 +703,14 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
 }
 
 // all (gate count, pre sign, post sign) kinds of one IO mode behind one scalar switch
-template <int IO, bool DEBUG>
+template <int IO, bool DEBUG, bool LT>
 __device__ __forceinline__ void stage_dispatch(uint32_t kind, double2* __restrict__ tile, const double2* __restrict__ Us,
                                                uint32_t my_rw, uint32_t my_sg, const uint32_t (&G)[10], int dbg,
                                                d2_t (&v)[16], uint32_t hbm_off, const uint32_t (&hbm_basis)[4],
                                                void* hbm_base, bool fin) {
 #define BORNVI_STAGE(NG, PRE, POST) \
   case (NG) | ((PRE) << 3) | ((POST) << 4): \
-    stage_body<NG, PRE, POST, IO, DEBUG>(tile, Us, my_rw, my_sg, G, dbg, v, hbm_off, hbm_basis, hbm_base, fin); break;
+    stage_body<NG, PRE, POST, IO, DEBUG, LT>(tile, Us, my_rw, my_sg, G, dbg, v, hbm_off, hbm_basis, hbm_base, fin); break;
 #define BORNVI_STAGE_NG(PRE, POST) \
   BORNVI_STAGE(0, PRE, POST) BORNVI_STAGE(1, PRE, POST) BORNVI_STAGE(2, PRE, POST) BORNVI_STAGE(3, PRE, POST) BORNVI_STAGE(4, PRE, POST)
   switch (kind) {
@@ -778,7 +889,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     const uint32_t kind_ = FS_[FS_KIND];   /* fused gates (register bits 0 .. ng-1) | pre sign << 3 | post sign << 4 */ \
     const uint32_t rw_ = tab_rw[(uint32_t)(S_) * T + t];                                                        \
     const uint32_t sg_ = (kind_ >> 3) ? tab_sg[(uint32_t)__popc(sign_any & ((1u << (S_)) - 1u)) * T + t] : 0u;  \
-    stage_dispatch<IO_, DEBUG>(kind_, tile, mats + (S_) * 16, rw_, sg_, G_, dbg, v, (IO_) == 2 ? tw_out[t] : 0u, \
+    stage_dispatch<IO_, DEBUG, SPLIT>(kind_, tile, mats + (S_) * 16, rw_, sg_, G_, dbg, v, (IO_) == 2 ? tw_out[t] : 0u, \
                                out_basis, hbm_base, fin);                                                       \
   } while (0)
   for (long long Tcur = (long long)blockIdx.x - (long long)gridDim.x;; Tcur += gridDim.x, parity ^= 1u) {
