@@ -335,26 +335,27 @@ bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& plan
   }
   spec.n_params = num_params(ansatz, n, layers);
   spec.n_gates = (int)gates.size();
-  if (opt.kmulti == 0 && n > opt.kmax && n >= 17 && opt.kmax >= 13) {
-    // Tile size by measurement on the MI355X (tools/tile_sweep_n.py): 2^13 tiles (one 512-thread
-    // workgroup per CU) run a stage ~10 % slower than 2^11 tiles (four 128-thread workgroups per CU), so they pay
-    // when they save at least one in eight of the HBM round trips -- at L = 6: n = 17 (9 -> 7), 19 (10 -> 8), 20 (11 -> 9)
-    // yes, n = 18 (9 -> 8) no -- and only where the fast kernel can run them (tables and tile within 160 KiB of LDS).
+  if (opt.kmulti == 0 && n > opt.kmax && opt.kmax >= 13) {
+    // Tile size by measurement on the MI355X (tools/tile_sweep_n.py).  Round 1: 2^13 tiles (one
+    // 512-thread workgroup per CU) ran a stage ~10 % slower than 2^11 tiles (four 128-thread workgroups per CU) and paid
+    // only where they saved an eighth of the HBM round trips.  With the large-tile instantiation of the kernel (prefetch
+    // spread over the stages, write-back folded into the last gate, matrix double-buffering) they are the fastest or
+    // tied for every multi-tile state: L = 6, k = 11 / 12 / 13: n = 14: 0.58 / 0.53 / 0.51 ms, 15: 1.25 / 1.09 / 1.11,
+    // 16: 2.40 / 2.39 / 2.30, 17: 5.45 / 4.95 / 4.80, 18: 11.2 / 12.0 / 11.2, 19: 29.3 / 25.3 / 23.6, 20: 78.9 / 59.5 / 55.0.
+    // So: 2^13 wherever the fast kernel can run them (tables and tile within 160 KiB of LDS), else 2^11.
     PlanOptions o11 = opt, o13 = opt;
     o11.kmulti = 11;
     o13.kmulti = 13;
-    Plan p11, p13;
-    std::string m11, m13;
-    const bool ok11 = build_plan(spec, o11, p11, m11), ok13 = build_plan(spec, o13, p13, m13);
-    bool take13 = ok13 && (!ok11 || p13.n_passes * 8 <= p11.n_passes * 7);
-    if (take13 && ok11) {
+    Plan p13;
+    std::string m13;
+    if (build_plan(spec, o13, p13, m13)) {
       FastTables ft;
-      take13 = build_fast_tables(p13, FAST_TABLE_MAX_BYTES, ft) && p13.fast_lds_bytes(ft.max_tab_rows) <= MAX_LDS_BYTES;
+      if (build_fast_tables(p13, FAST_TABLE_MAX_BYTES, ft) && p13.fast_lds_bytes(ft.max_tab_rows) <= MAX_LDS_BYTES) {
+        plan = std::move(p13);
+        return true;
+      }
     }
-    if (take13) { plan = std::move(p13); return true; }
-    if (ok11) { plan = std::move(p11); return true; }
-    msg = m11;
-    return false;
+    return build_plan(spec, o11, plan, msg);
   }
   return build_plan(spec, opt, plan, msg);
 }

@@ -125,9 +125,8 @@ constexpr size_t MAX_LDS_BYTES = 160 * 1024;   // per CU and per workgroup on gf
 struct PlanOptions {
   int kmax = 13;     // largest tile (2^13 complex128 = 128 KiB of LDS): a state of n <= kmax qubits is ONE tile
   int kmulti = 0;    // tile bits when the state needs several tiles (n > kmax).  0 = by measurement on MI355X
-                     // (DESIGN.md 4.1): 2^11 (32 KiB, four 128-thread workgroups per CU whose HBM, LDS and FMA
-                     // phases interleave) up to n = 16; above, 2^13 where that saves an eighth or more of the passes over the
-                     // (then HBM-resident) states, else 2^11 (make_plan)
+                     // (DESIGN.md 4.1): 2^13 (one 512-thread workgroup per CU, the large-tile instantiation of the
+                     // fast kernel) wherever the fast kernel can run it, else 2^11 (make_plan)
   int r = 4;         // register wires per stage (2^4 amplitudes per thread)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 512;

@@ -123,12 +123,13 @@ def test_full_size_plans_are_well_formed():
         for n, L in [(16, 6), (20, 8)]:
             W = _ext.plan_words(ansatz_id, n, L, 0)
             st = pe.plan_stats(W)
-            # tile size: 2^11 up to n = 16; above, 2^13 where it saves one pass in eight or more, else 2^11 (make_plan)
-            assert st["k"] == 11 if n <= 16 else st["k"] in (11, 13)
-            if n > 16:
-                p11 = pe.plan_stats(_ext.plan_words(ansatz_id, n, L, 11))["passes"]
-                p13 = pe.plan_stats(_ext.plan_words(ansatz_id, n, L, 13))["passes"]
-                assert st["passes"] == (p13 if st["k"] == 13 else p11) and (st["k"] == 11 or 8 * p13 <= 7 * p11)
+            # tile size of a multi-tile state: 2^13 wherever the fast kernel can run it (make_plan)
+            # (all_to_all at n = 20 carries CZ sign tables in every stage: tile + table rows exceed 160 KiB of LDS -> 2^11)
+            assert st["k"] == (11 if (ansatz_id, n) == (1, 20) else 13)
+            assert _ext.plan_fast_words(ansatz_id, n, L, 0)[0] is not None
+            p11 = pe.plan_stats(_ext.plan_words(ansatz_id, n, L, 11))["passes"]
+            p13 = pe.plan_stats(_ext.plan_words(ansatz_id, n, L, 13))["passes"]
+            assert st["passes"] == (p13 if st["k"] == 13 else p11) and p13 <= p11
             assert 2 <= st["passes"] <= 3 * L + 2
             assert int(W[8]) == len(W)
     assert _ext.lib().bornvi_plan_describe(0, 31, 1, 0, None, 0) == -1       # n out of range

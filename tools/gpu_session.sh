@@ -32,6 +32,7 @@ circ_ab() {
 }
 stamps() { for v in ${STAMP_LIBS:-stamps}; do BORNVI_LIB=$PWD/tools/_variants/libbornvi_circ_$v.so run 300 r2_stamp_probe_$v.log python tools/probes/stamp_probe.py; echo "--- $v"; grep -v amdgpu.ids gpurun_out/r2_stamp_probe_$v.log; done; }
 tests_circ_variant() { BORNVI_LIB=$PWD/tools/_variants/libbornvi_circ_${CIRC_VARIANT}.so run 600 r2_gpu_tests_circ_${CIRC_VARIANT}.log python -m pytest tests/test_gpu_circuit.py -m gpu -x -q; tail -n 4 gpurun_out/r2_gpu_tests_circ_${CIRC_VARIANT}.log; }
+tilesweep() { run 600 r2_tile_sweep.log python tools/tile_sweep_n.py; grep "^n=" gpurun_out/r2_tile_sweep.log; }
 rehearse() { for N in 2 4; do N=$N tools/rehearse_multi.sh; done; }
 emulate() { run 900 r2_emulate_ranks.log python tools/probes/emulate_ranks.py; grep "^n=" gpurun_out/r2_emulate_ranks.log; }
 pmc_sq() {

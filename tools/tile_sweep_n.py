@@ -5,7 +5,7 @@ import torch
 from tensornetworks_amd import backend as be
 dev = torch.device("cuda:0")
 L = 6
-for n in (17, 18, 19, 20):
+for n in (14, 15, 16, 17, 18, 19, 20):
     P = 3 * n * L
     th = torch.rand(P, dtype=torch.float64, device=dev)
     row = []
