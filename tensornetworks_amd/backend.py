@@ -292,8 +292,8 @@ def score_from_packed(packed, n, dev):
 
 
 def gram_ld(n):
-    """Row pitch (doubles) the library recommends for a dense K_p that the symmetric contraction will stream:
-    2^n + 32 for n >= 12 (a power-of-two pitch makes the row streams of a strip collide on one HBM channel), else 2^n."""
+    """Row pitch (doubles) the library recommends for a dense K_p: 2^n (padded pitches measured no faster; the `ld=`
+    arguments stay for a K_p embedded in a larger allocation)."""
     return int(_ext.lib().bornvi_stein_gram_ld(int(n)))
 
 
@@ -312,8 +312,8 @@ def _chk_matrix(K, rows, N, dev, name):
 
 def stein_gram(S, n, length_scale=1.0, rows=None, out=None, ld=None):
     """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard).
-    ld: row pitch in doubles (default 2^n: a contiguous matrix; gram_ld(n) for the padded layout the symmetric
-    contraction streams best) -- the result is then the [:, :2^n] view of a [rows, ld] buffer.
+    ld: row pitch in doubles (default 2^n: a contiguous matrix) -- with a larger pitch the result is the [:, :2^n] view
+    of a [rows, ld] buffer.
     out: a [rows, 2^n] float64 destination with unit column stride (e.g. rows of a larger, possibly padded, buffer)."""
     dev = S.device
     h = _ext.handle_for(dev)

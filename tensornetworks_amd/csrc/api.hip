@@ -629,10 +629,10 @@ int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, dou
 
 long long bornvi_stein_gram_ld(int n) {
   if (n < 1 || n > 17) return 0;
-  // Rows of a power-of-two pitch put the same column of every row into the same HBM channel and bank: the row streams
-  // of the symmetric contraction (32 per wave, all at the same column) then collide.  256 bytes of padding per row
-  // rotates consecutive rows over the channels.  Small matrices (a few MiB: cache-resident) stay dense.
-  return n >= 12 ? (1ll << n) + 32 : (1ll << n);
+  // The dense pitch.  Round 2 measured padded pitches (2^n + 32 ... 2^n + 4096 doubles) against the dense one on the
+  // band kernel: no difference (contraction) -- the pitch-taking entry points stay for callers
+  // that embed K_p in a larger allocation.
+  return 1ll << n;
 }
 
 int bornvi_stein_gram_build_rows_ld(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,

@@ -713,6 +713,9 @@ __device__ __forceinline__ void stage_dispatch(uint32_t kind, double2* __restric
     stage_body<NG, PRE, POST, IO, DEBUG, LT>(tile, Us, my_rw, my_sg, G, dbg, v, hbm_off, hbm_basis, hbm_base, fin); break;
 #define BORNVI_STAGE_NG(PRE, POST) \
   BORNVI_STAGE(0, PRE, POST) BORNVI_STAGE(1, PRE, POST) BORNVI_STAGE(2, PRE, POST) BORNVI_STAGE(3, PRE, POST) BORNVI_STAGE(4, PRE, POST)
+#if BORNVI_TIMING_NO_GATES   /* experiment (wrong results): the stages' LDS round trips and signs without the gate arithmetic */
+  kind &= ~7u;
+#endif
   switch (kind) {
     BORNVI_STAGE_NG(0, 0)
     BORNVI_STAGE_NG(1, 0)
@@ -990,7 +993,11 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
             BORNVI_RUN_STAGE(s, 2);
           } else {
             BORNVI_RUN_STAGE(s, 0);
+#if BORNVI_TIMING_NO_STAGE_BARRIER   /* experiment (wrong results): what the workgroup-wide barrier between stages costs */
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
             __syncthreads();
+#endif
           }
         }
       }

@@ -198,8 +198,7 @@ class KSDVariationalInference:
                 self._K_pairs = (pa, pb, l1 - l0)
 
                 def build():
-                    # (padded row pitch: backend.gram_ld -- the strips' row streams must not share an HBM channel)
-                    K = torch.empty(((l1 - l0) + (h1 - h0), backend.gram_ld(n)), dtype=torch.float64, device=dev)[:, : 1 << n]
+                    K = torch.empty(((l1 - l0) + (h1 - h0), 1 << n), dtype=torch.float64, device=dev)
                     if l1 > l0:
                         backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(l0, l1), out=K[: l1 - l0])
                         backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(h0, h1), out=K[l1 - l0:])
@@ -212,11 +211,7 @@ class KSDVariationalInference:
                 r0, r1 = self._K_rows
 
                 def build():
-                    # one GPU, symmetric contraction: padded row pitch (backend.gram_ld); the full-matrix and row-shard
-                    # kernels read contiguous rows
-                    pad = ws == 1 and self.symmetric_contraction
-                    return backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows,
-                                              ld=backend.gram_ld(n) if pad else None)
+                    return backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
 
                 def contract(K, q):
                     if ws == 1:

@@ -79,3 +79,40 @@ def bench_rank(rank, world_size, port, argv, out_dir):
         with open(os.path.join(out_dir, f"bench{rank}.err"), "w") as f:
             traceback.print_exc(file=f)
         raise
+
+
+def rccl_single_rank(rank, world_size, port, out_dir):
+    """A ONE-rank 'nccl' (= RCCL) group on cuda:0: the collective wrappers of paramshift_shard and the calls bench.py's
+    Dist makes, on device tensors, through RCCL itself (two ranks cannot share a GPU under RCCL, so the one-GPU box can
+    only check that the library initialises with `device_id=`, accepts float64 device tensors and returns the right
+    layout; the W > 1 arithmetic is what the gloo tests pin)."""
+    try:
+        _init(rank, world_size, port)
+        import torch
+        import torch.distributed as dist
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        try:
+            from tensornetworks_amd import paramshift_shard as shard
+            assert dist.get_backend() == "nccl" and shard.world() == (0, 1)
+            g = torch.Generator(device="cpu").manual_seed(3)
+            msg = torch.randn(4097, dtype=torch.float64, generator=g).to(dev)
+            out = torch.empty_like(msg)
+            shard.all_gather_flat(out, msg)
+            red = msg.clone()
+            shard.all_reduce_sum(red)
+            t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            objs = [None]
+            dist.all_gather_object(objs, {"circuits": 1.0})
+            dist.barrier()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(out, msg) and torch.equal(red, msg) and float(t.item()) == 1.25 and objs == [{"circuits": 1.0}])
+            np.savez(os.path.join(out_dir, "rccl.npz"), ok=np.bool_(ok))
+        finally:
+            dist.destroy_process_group()
+    except BaseException:
+        with open(os.path.join(out_dir, f"rank{rank}.err"), "w") as f:
+            traceback.print_exc(file=f)
+        raise

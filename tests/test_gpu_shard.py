@@ -107,3 +107,12 @@ def test_bench_dist_selftest_two_ranks(dev, tmp_path):
     ser = rec["series"][0]                                # the second workload measured beside the headline, same ranks
     assert ser["workload"] == "n8_L4_dense" and ser["n_gpus"] == 2 and ser["value"] > 0 and len(ser["phase_ms_per_rank"]) == 2
     assert not [l for l in open(tmp_path / "bench1.out").read().splitlines() if l.startswith("{")]   # rank 0 prints
+
+
+def test_rccl_group_of_one_runs_the_collective_wrappers(dev, tmp_path):
+    """RCCL itself (backend 'nccl', `device_id=` as bench.py passes it) on the one GPU of the box: a one-rank group runs
+    the all-gather / all-reduce wrappers and bench.py's MAX-reduce, object gather and barrier on float64 device
+    tensors."""
+    codes = run_ranks(shard_worker.rccl_single_rank, 1, (str(tmp_path),), timeout=300)
+    assert codes == [0], (codes, _errors(tmp_path))
+    assert bool(np.load(tmp_path / "rccl.npz")["ok"])

@@ -61,6 +61,7 @@ bench_small() { for w in n8_L4_dense n12_L4_dense; do run 300 r2_bench_$w.log py
 import json; r=json.load(open('gpurun_out/r2_bench_$w.json')); print('$w', r['value'], 'steps/s', r['ms_per_step'], 'ms', r['launch'], r['extras']['adjoint_engine'])"; done; }
 tests_adj() { run 600 r2_gpu_tests_adj.log python -m pytest tests/test_gpu_adjoint.py -m gpu -x -q; tail -n 25 gpurun_out/r2_gpu_tests_adj.log; }
 tests_stein() { run 600 r2_gpu_tests_stein.log python -m pytest tests/test_gpu_stein.py tests/test_gpu_shard.py tests/test_gpu_trainer.py -m gpu -x -q; tail -n 15 gpurun_out/r2_gpu_tests_stein.log; }
+tests_shard() { run 600 r2_gpu_tests_shard.log python -m pytest tests/test_gpu_shard.py -m gpu -x -q; tail -n 15 gpurun_out/r2_gpu_tests_shard.log; }
 tests() { run 900 r2_gpu_tests.log python -m pytest tests -m gpu -x -q; tail -n 30 gpurun_out/r2_gpu_tests.log; }
 bench() { run 600 r2_bench.log python bench.py --steps 20 --warmup 5; grep '^{' gpurun_out/r2_bench.log > gpurun_out/r2_bench.json; tail -c 3000 gpurun_out/r2_bench.log; }
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
