@@ -69,10 +69,12 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
 
 /* Tuning knobs of the circuit planner (clears the plan cache): "tile_bits" (4..13, amplitudes per
  * LDS tile = 2^tile_bits, for every n), "tile_bits_multi" (tile size used only when the state needs
- * several tiles; default 0 = chosen per plan: 11 up to n = 16, above that 13 where it saves an eighth of the passes), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
+ * several tiles; default 0 = chosen per plan: 13 wherever the persistent kernel can run such tiles, else 11), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
  * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
  * results are INVALID while non-zero).  Engine switches (no effect on results): "fast_path",
- * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus", "batched_quadform" (0: bornvi_stein_quadform
+ * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus", "alternate_walk" (default 1: odd passes
+ * walk the tiles of the batch from the last to the first, so that a pass starts on the states the previous one wrote last --
+ * the ones the memory-side cache still holds), "batched_quadform" (0: bornvi_stein_quadform
  * with B > 1 runs B GEMV passes instead of one matrix-core pass); "grad_engine" (default 0 = the reference's
  * parameter-shift rule; 1 = OPT-IN: bornvi_paramshift_grad answers with adjoint differentiation, see below);
  * "prefix_share" (default 0; 1: in

@@ -553,9 +553,18 @@ __device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void
 // The same for a direct last stage (IO == 2): the pair's two results go straight to HBM behind its gate -- the 16
 // stores of the tile are spread over the last gate instead of one burst per wave (a 1-KiB store takes ~100 cycles of the
 // CU's memory pipe).  Still exactly 16 stores per wave and tile, all behind the trip's loads.
-template <int I, bool POST>
+#ifndef BORNVI_FIN_HOIST
+#define BORNVI_FIN_HOIST 1      // one test of `fin` per last gate (two copies of the gate) instead of one per store: -1.3 %
+#endif
+template <int I, bool POST, int FIN = -1>
 __device__ __forceinline__ void op_u1_last_and_store(double (&ar)[16], double (&ai)[16], const double (&U)[8], uint32_t post_bits,
                                                      uint32_t ha0, const uint32_t (&hbm_basis)[4], void* hbm_base, bool fin) {
+  if (BORNVI_FIN_HOIST && FIN < 0) {
+    if (fin) op_u1_last_and_store<I, POST, 1>(ar, ai, U, post_bits, ha0, hbm_basis, hbm_base, true);
+    else op_u1_last_and_store<I, POST, 0>(ar, ai, U, post_bits, ha0, hbm_basis, hbm_base, false);
+    return;
+  }
+  if (FIN >= 0) fin = FIN != 0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     if (j & (1 << I)) continue;
@@ -895,10 +904,16 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     stage_dispatch<IO_, DEBUG, SPLIT>(kind_, tile, mats + (S_) * 16, rw_, sg_, G_, dbg, v, (IO_) == 2 ? tw_out[t] : 0u, \
                                out_basis, hbm_base, fin);                                                       \
   } while (0)
-  for (long long Tcur = (long long)blockIdx.x - (long long)gridDim.x;; Tcur += gridDim.x, parity ^= 1u) {
-    const bool real = Tcur >= 0;
-    const long long Tnext = Tcur + gridDim.x;
-    const bool has_next = Tnext < total_tiles;
+  // (direct_mask bit 2: this launch walks the tiles from the last to the first -- alternate passes in opposite directions
+  // start on the states the previous pass wrote last, i.e. on what the memory-side cache still holds)
+  const long long walk_flip = total_tiles - 1;
+  const bool walk_rev = (direct_mask & 4) != 0;
+  for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x, parity ^= 1u) {
+    const bool real = Scur >= 0;
+    const long long Snext = Scur + gridDim.x;
+    const bool has_next = Snext < total_tiles;
+    const long long Tcur = walk_rev ? walk_flip - Scur : Scur;       // (only used where `real`)
+    const long long Tnext = walk_rev ? walk_flip - Snext : Snext;    // (only used where `has_next`)
     if (!real && !has_next) break;
     const uint32_t g = real ? (uint32_t)(Tcur & ((1ll << gbits) - 1)) : 0u;
     const long long b = real ? (Tcur >> gbits) : 0;

@@ -26,7 +26,7 @@ def be(dev):
     from tensornetworks_amd import backend
     yield backend
     backend.set_option(dev, "tile_bits", 13)          # restore the planner defaults
-    backend.set_option(dev, "tile_bits_multi", 0)     # (0 = automatic: 2^11 tiles up to n = 16, 2^12 above)
+    backend.set_option(dev, "tile_bits_multi", 0)     # (0 = automatic: 2^13 tiles where the persistent kernel can run them)
 
 
 def gpu_probs(be, dev, ansatz, n, L, thetas):
@@ -272,6 +272,36 @@ def test_prefix_sharing_is_bit_identical(be, dev, ansatz, n, L, kb, monkeypatch)
         for sgn, row in ((+1, 1 + 2 * p_), (-1, 2 + 2 * p_)):
             t2 = th.copy(); t2[p_] += sgn * np.pi / 2
             np.testing.assert_allclose(got_full[row], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb,share", [(14, 3, 11, 0), (15, 2, 13, 0), (14, 2, 12, 1)])
+def test_alternate_walk_is_bit_identical(be, dev, ansatz, n, L, kb, share):
+    """Option alternate_walk (default on): odd passes walk the tiles of the batch from the last to the first (a pass
+    starts on the states the previous one wrote last).  Only the order of independent tiles changes: rows BITWISE equal
+    to the forward walk, with and without prefix sharing, for several tiles per workgroup (a batch of 2P + 1 circuits);
+    the forward rows agree with the oracle."""
+    be.set_option(dev, "tile_bits", kb)
+    P = oc.num_params(ansatz, n, L)
+    th = np.random.default_rng(5 * n + L).uniform(-np.pi, np.pi, P)
+    tht = torch.as_tensor(th, device=dev)
+    try:
+        be.set_option(dev, "prefix_share", share)
+        be.set_option(dev, "alternate_walk", 0)
+        fwd = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).cpu().numpy()
+        one = be.circuit_probs(ansatz, n, L, tht[None]).cpu().numpy()
+        be.set_option(dev, "alternate_walk", 1)
+        alt = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).cpu().numpy()
+        one_alt = be.circuit_probs(ansatz, n, L, tht[None]).cpu().numpy()
+    finally:
+        be.set_option(dev, "alternate_walk", 1)
+        be.set_option(dev, "prefix_share", 0)
+    np.testing.assert_array_equal(alt, fwd)
+    np.testing.assert_array_equal(one_alt, one)
+    np.testing.assert_array_equal(one[0], fwd[0])
+    np.testing.assert_allclose(fwd[0], oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)
+    t2 = th.copy(); t2[P - 1] -= np.pi / 2
+    np.testing.assert_allclose(alt[2 * P], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("n,L,kb", [(8, 2, 13), (14, 2, 11)])

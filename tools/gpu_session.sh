@@ -30,6 +30,7 @@ circ_ab() {
     BORNVI_LIB=$PWD/$lib run 300 r2_circ_ab_$v.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_$v.log
   done
 }
+circ_opts() { for o in ${CIRC_OPTS}; do BORNVI_OPTS=$o run 300 r2_circ_ab_opt_$o.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_opt_$o.log; done; }
 stamps() { for v in ${STAMP_LIBS:-stamps}; do BORNVI_LIB=$PWD/tools/_variants/libbornvi_circ_$v.so run 300 r2_stamp_probe_$v.log python tools/probes/stamp_probe.py; echo "--- $v"; grep -v amdgpu.ids gpurun_out/r2_stamp_probe_$v.log; done; }
 tests_circ_variant() { BORNVI_LIB=$PWD/tools/_variants/libbornvi_circ_${CIRC_VARIANT}.so run 600 r2_gpu_tests_circ_${CIRC_VARIANT}.log python -m pytest tests/test_gpu_circuit.py -m gpu -x -q; tail -n 4 gpurun_out/r2_gpu_tests_circ_${CIRC_VARIANT}.log; }
 tilesweep() { run 600 r2_tile_sweep.log python tools/tile_sweep_n.py; grep "^n=" gpurun_out/r2_tile_sweep.log; }
@@ -49,6 +50,23 @@ pmc_sq() {
   done
   cd /root/repo
 }
+pmc_circ() {   # instruction counts of the circuit engine, per pass: default build and every tools/_variants/libbornvi_circ_*.so
+  cd /tmp
+  for lib in default /root/repo/tools/_variants/libbornvi_circ_*.so; do
+    v=$(basename $lib .so); [ $lib = default ] || export BORNVI_LIB=$lib
+    for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_VALU" \
+               "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"; do
+      tag=${v}_$(echo $set | cut -d' ' -f1)
+      rm -rf /root/repo/gpurun_out/pmc_circ_$tag
+      timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d /root/repo/gpurun_out/pmc_circ_$tag -- \
+        python3 /root/repo/tools/probes/circuit_once.py > /root/repo/gpurun_out/pmc_circ_$tag.log 2>&1
+      rc=$?; echo "$tag rc=$rc"; [ $rc -ge 124 ] && exit 1
+      python3 /root/repo/tools/probes/pmc_rows.py "/root/repo/gpurun_out/pmc_circ_$tag/**/*counter_collection.csv" circuit_pass_fast | sed -n '1p;16,22p'
+    done
+  done
+  unset BORNVI_LIB
+  cd /root/repo
+}
 profile() {
   tools/prof_stats.sh r02_n16_L6_dense 2>&1 | tail -14
   tools/prof_stats.sh r02_n20_L8_kron --workload n20_L8_kron 2>&1 | tail -8
@@ -64,6 +82,13 @@ tests_stein() { run 600 r2_gpu_tests_stein.log python -m pytest tests/test_gpu_s
 tests_shard() { run 600 r2_gpu_tests_shard.log python -m pytest tests/test_gpu_shard.py -m gpu -x -q; tail -n 15 gpurun_out/r2_gpu_tests_shard.log; }
 tests() { run 900 r2_gpu_tests.log python -m pytest tests -m gpu -x -q; tail -n 30 gpurun_out/r2_gpu_tests.log; }
 bench() { run 600 r2_bench.log python bench.py --steps 20 --warmup 5; grep '^{' gpurun_out/r2_bench.log > gpurun_out/r2_bench.json; tail -c 3000 gpurun_out/r2_bench.log; }
+bench_ab() {   # the headline step with backend options switched (BENCH_AB_OPTS="name=value ..."), same box: A B A B
+  for rep in 1 2; do for o in default ${BENCH_AB_OPTS}; do
+    arg=""; [ $o = default ] || arg="--opt $o"
+    run 300 r2_bench_ab_${o}_$rep.log python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gate-bench --no-extras --series none $arg
+    grep '^{' gpurun_out/r2_bench_ab_${o}_$rep.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$o', r['value'], r['ms_per_step'], r['phase_ms']['circuits'], r['phase_ms']['stein'])"
+  done; done
+}
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
            run 300 r2_stream_probe_rand.log tools/_variants/stream_probe 3 0 1; cat gpurun_out/r2_stream_probe_rand.log; }

@@ -10,6 +10,10 @@ from tensornetworks_amd import backend
 
 dev = torch.device("cuda", 0)
 tag = os.path.basename(os.environ.get("BORNVI_LIB", "default"))
+for kv in filter(None, os.environ.get("BORNVI_OPTS", "").split(",")):     # e.g. BORNVI_OPTS=alternate_walk=1
+    name, value = kv.split("=")
+    backend.set_option(dev, name, int(value))
+    tag += f" {name}={value}"
 for n, L in ((16, 6), (20, 8)):
     P = backend.num_params("hardware_efficient", n, L)
     g = torch.Generator().manual_seed(0)
