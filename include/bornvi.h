@@ -166,10 +166,11 @@ int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, co
                                  long long row_begin, long long row_end, double* K_rows,
                                  bornvi_stream stream);
 
-/* Row pitch.  The `_ld` entry points take K_p with any even row pitch in [2^n, 2^n + 4096] doubles (a matrix embedded
- * in a larger allocation); columns >= 2^n of a row are never read or written.  bornvi_stein_gram_ld(n) is the pitch
- * the library recommends: the dense one, 2^n (padded pitches measured no faster on the band kernel; 0 for n outside
- * [1, 17]). */
+/* Padded row pitch.  K_p with a power-of-two row pitch puts the same column of every row into the same HBM channel and
+ * bank, and the symmetric contraction streams 32 rows per wave at the same column; bornvi_stein_gram_ld(n) is the
+ * pitch (in doubles, >= 2^n, even) the library recommends: 2^n + 32 for n >= 12, else 2^n (n = 16: 2.56 ms on every
+ * allocation against 2.62 ... 2.83 ms dense; 0 for n outside [1, 17]).  The `_ld` entry points take any even pitch in
+ * [2^n, 2^n + 4096]; columns >= 2^n of a row are never read or written. */
 long long bornvi_stein_gram_ld(int n);
 int bornvi_stein_gram_build_rows_ld(bornvi_handle h, int n, double length_scale, const double* S,
                                     long long row_begin, long long row_end, double* K_rows, long long ld,

@@ -14,6 +14,7 @@ from . import _ext
 from ._ext import ANSATZ_IDS, BornviError
 
 _workspaces = {}
+_ws_windows = {}     # key -> (byte offset, bytes): tools/probes place a workspace inside another buffer through this
 
 # Cap for the circuit workspace (bytes); larger batches are processed in chunks by the library.
 WORKSPACE_CAP = int(os.environ.get("BORNVI_WORKSPACE_CAP", str(48 << 30)))
@@ -40,12 +41,22 @@ def num_params(ansatz_type, n, layers):
     return _ext.lib().bornvi_num_params(ansatz_id(ansatz_type), n, layers)
 
 
+def _ws_key(dev, tag):
+    return (dev.index, tag, int(torch.cuda.current_stream(dev).cuda_stream))
+
+
 def _ws(dev, nbytes, tag="main"):
     """Cached workspace, one per (device, purpose, STREAM): a buffer is only ever used on the stream it was allocated
     on, so the caching allocator's stream-ordered reuse stays valid when a workspace is re-grown (the overlap modes
     launch on auxiliary / CU-masked streams)."""
-    key = (dev.index, tag, int(torch.cuda.current_stream(dev).cuda_stream))
+    key = _ws_key(dev, tag)
     buf = _workspaces.get(key)
+    win = _ws_windows.get(key)
+    if buf is not None and win is not None:        # (probes only: a chosen window of a larger buffer)
+        if win[1] >= nbytes:
+            return buf[win[0]: win[0] + win[1]]
+        del _ws_windows[key]
+        buf = None
     if buf is None or buf.numel() < nbytes:
         _workspaces[key] = None
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
@@ -55,6 +66,7 @@ def _ws(dev, nbytes, tag="main"):
 
 def release_workspaces():
     _workspaces.clear()
+    _ws_windows.clear()
 
 
 def _chk(t, dtype, dev, name, numel=None):
@@ -292,8 +304,9 @@ def score_from_packed(packed, n, dev):
 
 
 def gram_ld(n):
-    """Row pitch (doubles) the library recommends for a dense K_p: 2^n (padded pitches measured no faster; the `ld=`
-    arguments stay for a K_p embedded in a larger allocation)."""
+    """Row pitch (doubles) the library recommends for a dense K_p that the symmetric contraction will stream:
+    2^n + 32 for n >= 12 (a power-of-two pitch makes the row streams of a band collide on one HBM channel: n = 16
+    2.56 ms padded against 2.62 ... 2.83 ms dense, by allocation), else 2^n."""
     return int(_ext.lib().bornvi_stein_gram_ld(int(n)))
 
 
@@ -312,8 +325,8 @@ def _chk_matrix(K, rows, N, dev, name):
 
 def stein_gram(S, n, length_scale=1.0, rows=None, out=None, ld=None):
     """Dense K_p [2^n, 2^n], or only its rows [rows[0], rows[1]) (one rank's block of a row shard).
-    ld: row pitch in doubles (default 2^n: a contiguous matrix) -- with a larger pitch the result is the [:, :2^n] view
-    of a [rows, ld] buffer.
+    ld: row pitch in doubles (default 2^n: a contiguous matrix; gram_ld(n) for the padded layout the symmetric
+    contraction streams best) -- the result is then the [:, :2^n] view of a [rows, ld] buffer.
     out: a [rows, 2^n] float64 destination with unit column stride (e.g. rows of a larger, possibly padded, buffer)."""
     dev = S.device
     h = _ext.handle_for(dev)
@@ -429,6 +442,11 @@ def stein_quadform(K, Q, n, want_y=True):
     h.call("bornvi_stein_quadform", n, _ptr(K), _ptr(Q2), B, _ptr(ksd2), _ptr(Y) if want_y else None, _ptr(ws),
            ws.numel(), _ext.stream_ptr(dev))
     return ksd2, Y
+
+
+def stein_sym_workspace_bytes(dev, n):
+    """Workspace bytes of the symmetric contraction (stein_quadform_sym / _pairs) at this n."""
+    return int(_cached_size(_ext.handle_for(dev), "bornvi_stein_quadform_sym_workspace_bytes", int(n)))
 
 
 def stein_quadform_sym(K, q, n):

@@ -633,10 +633,12 @@ int bornvi_score_from_cpts(bornvi_handle h, const bornvi_bn_desc* bn, int n, dou
 
 long long bornvi_stein_gram_ld(int n) {
   if (n < 1 || n > 17) return 0;
-  // The dense pitch.  Round 2 measured padded pitches (2^n + 32 ... 2^n + 4096 doubles) against the dense one on the
-  // band kernel: no difference (contraction) -- the pitch-taking entry points stay for callers
-  // that embed K_p in a larger allocation.
-  return 1ll << n;
+  // 256 bytes of padding per row.  Same-box A/B of the band kernel at n = 16 (tools/probes/sym_probe.py, three
+  // matrices held at once, twice): pitch 2^n: 2.62 / 2.83 / 2.63 and 2.83 / 2.62 / 2.63 ms by allocation; pitch
+  // 2^n + 32: 2.57 / 2.57 / 2.56 and 2.57 / 2.57 / 2.56 ms -- faster, and the dependence on where the matrix landed
+  // is gone.  (With a power-of-two pitch the same column of every row maps to the same HBM channel and bank, and a wave
+  // streams 32 rows at the same column.)  Small matrices (a few MiB: cache-resident) stay dense.
+  return n >= 12 ? (1ll << n) + 32 : (1ll << n);
 }
 
 int bornvi_stein_gram_build_rows_ld(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,

@@ -538,16 +538,35 @@ __device__ __forceinline__ void op_u1_last_and_write(double (&ar)[16], double (&
 // loop-carried variable.  As a plain output ("=v") the compiler may give the asm a fresh register and COPY it into
 // the variable's register right behind the asm statement -- i.e. before the data has arrived (seen on gfx950: the
 // second tile of every workgroup was computed from stale registers).
+// cache-policy bits of the tile loads / stores (A/B switches: 0 none, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt).  Every byte of a
+// state is read once and written once per pass: non-temporal on both sides.  Same-box A/B (tools/probes/circuit_ab.py),
+// batch of n = 16, L = 6 / n = 20, L = 8: none 2.150 / 95.7 ms; loads nt 2.065 / 95.1; stores nt 2.139 / 94.3; both
+// 2.080 / 93.9; loads sc1 2.149 / 95.6; loads sc1 nt 2.112 / 95.0; loads nt + stores sc1 2.169 / 94.6.
+#ifndef BORNVI_LOAD_POLICY
+#define BORNVI_LOAD_POLICY 1
+#endif
+#ifndef BORNVI_STORE_POLICY
+#define BORNVI_STORE_POLICY 1
+#endif
+#define BORNVI_POLICY_STR_0 ""
+#define BORNVI_POLICY_STR_1 " nt"
+#define BORNVI_POLICY_STR_2 " sc1"
+#define BORNVI_POLICY_STR_3 " sc0 sc1"
+#define BORNVI_POLICY_STR_4 " sc1 nt"
+#define BORNVI_POLICY_CAT_(X_) BORNVI_POLICY_STR_##X_
+#define BORNVI_POLICY_CAT(X_) BORNVI_POLICY_CAT_(X_)
+#define BORNVI_LOAD_MOD BORNVI_POLICY_CAT(BORNVI_LOAD_POLICY)
+#define BORNVI_STORE_MOD BORNVI_POLICY_CAT(BORNVI_STORE_POLICY)
 __device__ __forceinline__ void async_load16(d2_t& dst, uint32_t byte_off, const void* base) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(byte_off), "s"(base) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2" BORNVI_LOAD_MOD : "+v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
 // (the s_nop covers the "VMEM store of more than 64 bits, then VALU write of its data registers" hazard: the
 // compiler pads its own stores but does not look inside inline asm, and it reuses the data registers at once)
 __device__ __forceinline__ void async_store16(uint32_t byte_off, d2_t val, void* base) {
-  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2" BORNVI_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
 }
 __device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void* base) {
-  asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, %2" BORNVI_STORE_MOD : : "v"(byte_off), "v"(val), "s"(base) : "memory");
 }
 
 // The same for a direct last stage (IO == 2): the pair's two results go straight to HBM behind its gate -- the 16
@@ -1152,19 +1171,26 @@ __global__ __launch_bounds__(SHIFT_DOT_THREADS) void shift_dot_kernel(const doub
     // 16-byte loads, four pairs in flight per thread: one workgroup (16 waves) per parameter streams its two
     // probability vectors at the CU's full rate
     const long long N2 = N >> 1;
-    const double2* __restrict__ qp2 = reinterpret_cast<const double2*>(qp);
-    const double2* __restrict__ qm2 = reinterpret_cast<const double2*>(qm);
+    // (the two rows are read once: non-temporal loads; w is shared by every workgroup and stays cached)
+    const d2_t* __restrict__ qp2 = reinterpret_cast<const d2_t*>(qp);
+    const d2_t* __restrict__ qm2 = reinterpret_cast<const d2_t*>(qm);
     const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
     long long z = threadIdx.x;
     for (; z + 3 * SHIFT_DOT_THREADS < N2; z += 4 * SHIFT_DOT_THREADS) {
-      double2 a[4], b[4], c[4];
+      d2_t a[4], b[4];
+      double2 c[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a[u] = qp2[z + u * SHIFT_DOT_THREADS]; b[u] = qm2[z + u * SHIFT_DOT_THREADS]; c[u] = w2[z + u * SHIFT_DOT_THREADS]; }
+      for (int u = 0; u < 4; ++u) {
+        a[u] = __builtin_nontemporal_load(qp2 + z + u * SHIFT_DOT_THREADS);
+        b[u] = __builtin_nontemporal_load(qm2 + z + u * SHIFT_DOT_THREADS);
+        c[u] = w2[z + u * SHIFT_DOT_THREADS];
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc += c[u].x * (a[u].x - b[u].x) + c[u].y * (a[u].y - b[u].y);
     }
     for (; z < N2; z += SHIFT_DOT_THREADS) {
-      const double2 a = qp2[z], b = qm2[z], c = w2[z];
+      const d2_t a = __builtin_nontemporal_load(qp2 + z), b = __builtin_nontemporal_load(qm2 + z);
+      const double2 c = w2[z];
       acc += c.x * (a.x - b.x) + c.y * (a.y - b.y);
     }
   } else {

@@ -493,6 +493,9 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 #ifndef BORNVI_SYM_ABLATE      // timing-only builds (tools/probes): 2 = no column part at all (results invalid)
 #define BORNVI_SYM_ABLATE 0
 #endif
+#ifndef BORNVI_SYM_DEFER_STORE
+#define BORNVI_SYM_DEFER_STORE 1   // 0: store a trip's column partial at once (A/B)
+#endif
 #ifndef BORNVI_SYM_WAVES
 #define BORNVI_SYM_WAVES 8     // measured on six 32 GiB allocations held at once: 2.66-2.82 ms (8 waves) vs 2.66-2.94 ms (4)
 #endif
@@ -530,10 +533,16 @@ __device__ __forceinline__ sym_d2 sym_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
 
 // One trip of a wave over CH 128-column chunks starting at column cb: 32 rows x CH chunks, RB rows per batch of loads.
 // acc[r] += sum_j K_rj q4_j (row part); z[c] = sum_r K_rj q_r (column part of this trip).
-template <int CH, int RB>
+// PEND: the column partial of the PREVIOUS trip (`pend` -> *pend_ptr) is stored here, BEHIND this trip's first batch of
+// loads.  On CDNA the vmcnt counter retires loads and stores in issue order: a store issued between two trips sits in
+// front of the next trip's loads, and the first s_waitcnt for those loads also waits for the store's acknowledgement --
+// one exposed write latency per trip (microseconds while the read stream saturates the memory system, and dependent on
+// which channels the workspace and K_p share: that was the "placement" effect, tools/probes/ws_place_probe.py).  Behind
+// the first batch the store has the rest of the trip to complete before anything waits on it.
+template <int CH, int RB, bool PEND = false>
 __device__ __forceinline__ void sym_trip(__amdgpu_buffer_rsrc_t rsrc, long long ld, unsigned vlane, long long cb,
                                          const double2 (&q4)[CH], double (&acc)[SYM_ROWS], const double (&qi)[SYM_ROWS],
-                                         double (&z)[CH][2]) {
+                                         double (&z)[CH][2], double pend = 0.0, double* pend_ptr = nullptr) {
   unsigned ld8 = (unsigned)(ld * 8);
   asm volatile("" : "+s"(ld8));      // row offsets are formed per trip by the scalar unit (hoisted they spill: 32 x CH values)
   unsigned soff[CH];
@@ -546,6 +555,7 @@ __device__ __forceinline__ void sym_trip(__amdgpu_buffer_rsrc_t rsrc, long long 
     for (int u = 0; u < RB; ++u)
 #pragma unroll
       for (int c = 0; c < CH; ++c) kv[u][c] = sym_load16(rsrc, vlane, soff[c] + (unsigned)(r0 + u) * ld8);
+    if (PEND && r0 == 0) *pend_ptr = pend;
 #pragma unroll
     for (int u = 0; u < RB; ++u)
 #pragma unroll
@@ -593,6 +603,10 @@ __device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb 
   const long long t0 = (part * tp < ntrips) ? part * tp : ntrips;
   const long long t1 = (t0 + tp < ntrips) ? t0 + tp : ntrips;
   double* __restrict__ Z2s = Z2 + sym_z2_offset(S, N) - bulk0;            // Z2s[j]
+  constexpr bool DEFER = SYM_WAVES == 8 && BORNVI_SYM_ABLATE < 2 && BORNVI_SYM_DEFER_STORE;
+  // (deferred store, see sym_trip: the first trip "stores" 0.0 to the address its own result goes to one trip later)
+  double pend = 0.0;
+  double* pend_ptr = Z2s + (bulk0 + t0 * 512) + (wave * 64 + lane);
 #pragma unroll 1
   for (long long t = t0; t < t1; ++t) {
     const long long cb = bulk0 + t * 512;
@@ -600,7 +614,7 @@ __device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb 
 #pragma unroll
     for (int c = 0; c < 4; ++c) q4[c] = *reinterpret_cast<const double2*>(q + cb + c * 128 + lane * 2);
     double z[4][2];
-    sym_trip<4, 8>(rsrc, ld, vlane, cb, q4, acc, qi, z);
+    sym_trip<4, 8, DEFER>(rsrc, ld, vlane, cb, q4, acc, qi, z, pend, pend_ptr);
     if (BORNVI_SYM_ABLATE < 2) {
       const int buf = (int)((t - t0) & 1);
 #pragma unroll
@@ -615,10 +629,12 @@ __device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb 
         double sum = 0.0;
 #pragma unroll
         for (int w2 = 0; w2 < SYM_WAVES; w2 += 2) sum += zb[w2 * 512 + tid] + zb[(w2 + 1) * 512 + tid];
-        Z2s[cb + tid] = sum;
+        if (DEFER) { pend = sum; pend_ptr = Z2s + cb + tid; }
+        else Z2s[cb + tid] = sum;
       }
     }
   }
+  if (DEFER && t1 > t0) *pend_ptr = pend;
   __syncthreads();      // the LDS buffers are reused by the next band of this workgroup
 #pragma unroll
   for (int r = 0; r < SYM_ROWS; ++r) {

@@ -137,8 +137,14 @@ class KSDVariationalInference:
         # one forward and one backward walk over the gates (bornvi_adjoint_state / _vjp) -- the same gradient to
         # rounding from about three circuit evaluations; every rank computes it whole (nothing to shard).
         self.grad_engine = "paramshift"
-        self.gram_placement_tries = 1       # (> 1: build that many copies of a dense K_p >= 1 GiB and keep the one the
-                                            # contraction streams fastest -- the round-1 workaround, off by default)
+        # A dense K_p >= 1 GiB is placed by measurement: up to this many copies are built (each in fresh memory while the
+        # earlier ones are held), the contraction is timed on each, the fastest stays (_place_gram).  The contraction's
+        # rate depends on where the driver put K_p RELATIVE to the workspace its partial sums go to -- 2.55 or 2.78 ms
+        # at n = 16 for the same kernel and matrix, stable for the life of the allocations, equal alone and inside the
+        # training step (tools/probes/step_placement_probe.py, ws_place_probe.py, ws_far_probe.py) -- and a process
+        # cannot see physical addresses.  One-time cost: ~50 ms and 2^(2n+3) bytes per extra copy, freed at once; the
+        # search stops as soon as a fast and a slow placement have both been seen.  1 = take the first copy.
+        self.gram_placement_tries = 4
         self.gram_placement = None          # {"contraction_ms_per_try": [...], "kept": index} of the last _prepare_stein
         self._aux_stream = None
 
@@ -198,7 +204,8 @@ class KSDVariationalInference:
                 self._K_pairs = (pa, pb, l1 - l0)
 
                 def build():
-                    K = torch.empty(((l1 - l0) + (h1 - h0), 1 << n), dtype=torch.float64, device=dev)
+                    # (padded row pitch: backend.gram_ld -- the strips' row streams must not share an HBM channel)
+                    K = torch.empty(((l1 - l0) + (h1 - h0), backend.gram_ld(n)), dtype=torch.float64, device=dev)[:, : 1 << n]
                     if l1 > l0:
                         backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(l0, l1), out=K[: l1 - l0])
                         backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=(h0, h1), out=K[l1 - l0:])
@@ -211,7 +218,11 @@ class KSDVariationalInference:
                 r0, r1 = self._K_rows
 
                 def build():
-                    return backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows)
+                    # one GPU, symmetric contraction: padded row pitch (backend.gram_ld); the full-matrix and row-shard
+                    # kernels read contiguous rows
+                    pad = ws == 1 and self.symmetric_contraction
+                    return backend.stein_gram(self._S, n, self.base_kernel_length_scale, rows=self._K_rows,
+                                              ld=backend.gram_ld(n) if pad else None)
 
                 def contract(K, q):
                     if ws == 1:
@@ -222,11 +233,13 @@ class KSDVariationalInference:
 
     def _place_gram(self, build, contract):
         """Builds K_p and, for large matrices, picks a well-placed copy.  The contraction streams the matrix from HBM
-        and its rate depends on WHERE the driver put it: on the MI355X pool two allocations of the same 32 GiB in one
-        process stream at 6.0 and 5.2 TB/s (2.84 / 3.32 ms per contraction at n = 16, stable for the life of the
-        allocation, independent of the virtual address or an offset inside it -- tools/contraction_variance_probe.py).
+        and its rate depends on where the driver put it relative to the contraction's workspace: round 2, same kernel,
+        same box, n = 16: 2.55 ms or 2.78 ms, stable for the life of the two allocations, the same alone and inside the
+        training step, following the (K_p, workspace) PAIR -- a workspace inside K_p's own allocation is always the
+        slow case (tools/probes/ws_in_kp_probe.py), one 64+ GiB further on usually the fast one (ws_far_probe.py).
+        (Round 1's 2.84 / 3.32 ms were the same effect amplified by 8x more partial-sum stores.)
         So: build up to `gram_placement_tries` copies (each in fresh memory while the earlier ones are still held), time
-        the contraction on each, keep the fastest, free the rest.  Same matrix, same results; ~30 ms per extra try."""
+        the contraction on each, keep the fastest, free the rest.  Same matrix, same results; ~50 ms per extra try."""
         K = build()
         nbytes = K.numel() * K.element_size()
         tries = int(self.gram_placement_tries)
@@ -250,7 +263,7 @@ class KSDVariationalInference:
 
         cands = [(clock(K), K)]
         while len(cands) < tries and free_b > (len(cands) + 1) * nbytes + (8 << 30):
-            if min(t for t, _ in cands) < 0.93 * max(t for t, _ in cands):
+            if min(t for t, _ in cands) < 0.95 * max(t for t, _ in cands):
                 break                                       # a fast and a slow placement have both been seen
             Kn = build()
             cands.append((clock(Kn), Kn))

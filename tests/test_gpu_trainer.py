@@ -263,7 +263,8 @@ def test_gram_placement_keeps_an_identical_matrix(dev):
     n = 14                                                       # 2 GiB of K_p
     bn, lat, obs, x = synthetic_network(n, seed=2)
     vi = make_vi(bn, lat, obs, n, 1, "hardware_efficient", str(dev), gram_mode="dense")
-    vi.gram_placement_tries = 3          # (off by default since the padded row pitch; still selectable)
+    assert vi.gram_placement_tries >= 2  # (on by default: the contraction's rate follows the placement of K_p vs its workspace)
+    vi.gram_placement_tries = 3
     vi._prepare_stein(x)
     gp = vi.gram_placement
     assert gp is not None and 1 <= len(gp["contraction_ms_per_try"]) <= vi.gram_placement_tries

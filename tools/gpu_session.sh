@@ -22,6 +22,24 @@ sym() {
     grep -v amdgpu.ids gpurun_out/r2_sym_probe_$v.log
   done
 }
+sym_default() { PADS=${PADS:-0,32,0,32} ALLOCS=${ALLOCS:-3} run 400 r2_sym_probe_default.log python tools/probes/sym_probe.py; grep -v amdgpu.ids gpurun_out/r2_sym_probe_default.log; }
+step_place() { run 600 r2_step_placement.log python tools/probes/step_placement_probe.py; grep "^copy" gpurun_out/r2_step_placement.log; }
+sym_place() {   # contraction alone on ALLOCS padded copies of K_p: default build, then every tools/_variants/libbornvi_sym_*.so
+  for lib in default tools/_variants/libbornvi_sym_*.so; do
+    v=$(basename $lib .so); unset BORNVI_LIB; [ $lib = default ] || export BORNVI_LIB=$PWD/$lib
+    PADS=${PADS:-32} ALLOCS=${ALLOCS:-7} run 400 r2_sym_place_$v.log python tools/probes/sym_probe.py; grep "pad=" gpurun_out/r2_sym_place_$v.log
+  done; unset BORNVI_LIB
+}
+ws_place() { run 400 r2_ws_place.log python tools/probes/ws_place_probe.py; grep "^K_p" gpurun_out/r2_ws_place.log; }
+sym_trace() {   # which kernel carries the allocation-dependent time: main kernel or reduce?
+  cd /tmp; rm -rf /root/repo/gpurun_out/sym_trace
+  PADS=32 ALLOCS=${ALLOCS:-6} timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/sym_trace -- python3 /root/repo/tools/probes/sym_probe.py > /root/repo/gpurun_out/r2_sym_trace.log 2>&1
+  rc=$?; echo "rc=$rc"; [ $rc -ge 124 ] && exit 1
+  cd /root/repo; grep "pad=" gpurun_out/r2_sym_trace.log
+  python tools/probes/kernel_durations.py 'gpurun_out/sym_trace/**/*kernel_trace.csv' 18 quadform_sym_kernel quadform_sym_reduce_kernel
+}
+ws_in_kp() { run 400 r2_ws_in_kp.log python tools/probes/ws_in_kp_probe.py; grep "^copy" gpurun_out/r2_ws_in_kp.log; FRONT=1 run 400 r2_ws_in_kp_front.log python tools/probes/ws_in_kp_probe.py; grep "^copy" gpurun_out/r2_ws_in_kp_front.log; }
+ws_far() { run 500 r2_ws_far.log python tools/probes/ws_far_probe.py; grep -A1 "^K_p" gpurun_out/r2_ws_far.log; }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
 circ_ab() {
   run 300 r2_circ_ab_default.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_default.log
@@ -88,6 +106,13 @@ bench_ab() {   # the headline step with backend options switched (BENCH_AB_OPTS=
     run 300 r2_bench_ab_${o}_$rep.log python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gate-bench --no-extras --series none $arg
     grep '^{' gpurun_out/r2_bench_ab_${o}_$rep.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$o', r['value'], r['ms_per_step'], r['phase_ms']['circuits'], r['phase_ms']['stein'])"
   done; done
+}
+bench_libs() {   # the headline step with other builds of the library (tools/_variants/libbornvi_circ_*.so), same box: A B A B
+  for rep in 1 2; do for lib in default tools/_variants/libbornvi_circ_*.so; do
+    v=$(basename $lib .so); unset BORNVI_LIB; [ $lib = default ] || export BORNVI_LIB=$PWD/$lib
+    run 300 r2_bench_lib_${v}_$rep.log python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gate-bench --no-extras --series none
+    grep '^{' gpurun_out/r2_bench_lib_${v}_$rep.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$v', r['value'], r['ms_per_step'], r['phase_ms']['circuits'], r['phase_ms']['stein'], r['phase_ms']['finish'])"
+  done; done; unset BORNVI_LIB
 }
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log

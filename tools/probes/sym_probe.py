@@ -32,7 +32,7 @@ for pad in [int(x) for x in os.environ.get("PADS", "0,32,64,160").split(",")]:
         if ref is None:
             ref = (k2.clone(), y.clone())
         else:
-            assert torch.equal(y, ref[1]) and torch.equal(k2, ref[0]), "results differ between pitches / allocations"
+            assert os.environ.get("NOCHECK") or (torch.equal(y, ref[1]) and torch.equal(k2, ref[0])), "results differ between pitches / allocations"
     bytes_ = 4.0 * N * (N + 32)
     print(f"{tag} n={n} pad={pad:4d} ms per allocation {[round(t, 4) for t in times]}  best {bytes_ / min(times) / 1e6:.0f} GB/s  worst {bytes_ / max(times) / 1e6:.0f} GB/s", flush=True)
     del held, K
