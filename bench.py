@@ -228,6 +228,8 @@ def make_vi(workload, dev, process_group=None, overlap=0):
                                  process_group=process_group)
     if overlap >= 0:
         vi.overlap_streams = {0: False, 1: True, 2: "partition"}[overlap]
+    if int(os.environ.get("BORNVI_PLACEMENT_TRIES", "-1")) >= 0:      # A/B of the K_p placement selection (default: the trainer's)
+        vi.gram_placement_tries = int(os.environ["BORNVI_PLACEMENT_TRIES"])
     g = torch.Generator().manual_seed(0)
     P = vi.born_machine.num_ansatz_params
     with torch.no_grad():     # theta0 = 0.1 * randn(P) float32, `small_random` (quantum_born_machine.py:43-45)

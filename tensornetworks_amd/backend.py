@@ -64,6 +64,19 @@ def _ws(dev, nbytes, tag="main"):
     return buf
 
 
+def fresh_workspace(dev, nbytes):
+    """A new device buffer that can be installed as a workspace (set_workspace)."""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+
+
+def set_workspace(dev, tag, buf):
+    """Makes `buf` the cached workspace `tag` of the current stream (the trainer places the symmetric contraction's
+    workspace by measurement: KSDVariationalInference._place_gram)."""
+    key = _ws_key(dev, tag)
+    _ws_windows.pop(key, None)
+    _workspaces[key] = buf
+
+
 def release_workspaces():
     _workspaces.clear()
     _ws_windows.clear()

@@ -145,7 +145,7 @@ class KSDVariationalInference:
         # cannot see physical addresses.  One-time cost: ~50 ms and 2^(2n+3) bytes per extra copy, freed at once; the
         # search stops as soon as a fast and a slow placement have both been seen.  1 = take the first copy.
         self.gram_placement_tries = 4
-        self.gram_placement = None          # {"contraction_ms_per_try": [...], "kept": index} of the last _prepare_stein
+        self.gram_placement = None          # {"contraction_ms_per_pair": [[copy, workspace, ms], ...], "kept": [copy, workspace]}
         self._aux_stream = None
 
     # ---- reference attribute kept lazily (2^n Python tuples) -------------------------------------------
@@ -228,18 +228,21 @@ class KSDVariationalInference:
                     if ws == 1:
                         return backend.stein_quadform_sym(K, q, n) if self.symmetric_contraction else backend.stein_quadform(K, q, n, want_y=True)
                     return backend.stein_quadform_rows(K, r0, r1, q, n)
-            self._K = self._place_gram(build, contract)
+            sym = self.symmetric_contraction and (ws == 1 or sp is not None)
+            self._K = self._place_gram(build, contract, backend.stein_sym_workspace_bytes(dev, n) if sym else 0)
         self._stein_key = self._key(x_dict)
 
-    def _place_gram(self, build, contract):
+    def _place_gram(self, build, contract, ws_bytes=0):
         """Builds K_p and, for large matrices, picks a well-placed copy.  The contraction streams the matrix from HBM
         and its rate depends on where the driver put it relative to the contraction's workspace: round 2, same kernel,
         same box, n = 16: 2.55 ms or 2.78 ms, stable for the life of the two allocations, the same alone and inside the
         training step, following the (K_p, workspace) PAIR -- a workspace inside K_p's own allocation is always the
         slow case (tools/probes/ws_in_kp_probe.py), one 64+ GiB further on usually the fast one (ws_far_probe.py).
         (Round 1's 2.84 / 3.32 ms were the same effect amplified by 8x more partial-sum stores.)
-        So: build up to `gram_placement_tries` copies (each in fresh memory while the earlier ones are still held), time
-        the contraction on each, keep the fastest, free the rest.  Same matrix, same results; ~50 ms per extra try."""
+        So: build up to `gram_placement_tries` copies (each in fresh memory while the earlier ones are still held), and
+        behind each a fresh workspace (`ws_bytes` > 0: the symmetric contraction's, which then lies one matrix further
+        on than the last), time the contraction on every (copy, workspace) pair, keep the fastest pair, free the rest.
+        Same matrix, same results; stops as soon as a clearly fast and a slow pair have both been seen."""
         K = build()
         nbytes = K.numel() * K.element_size()
         tries = int(self.gram_placement_tries)
@@ -261,18 +264,34 @@ class KSDVariationalInference:
             torch.cuda.synchronize(dev)
             return a.elapsed_time(b) / 3
 
-        cands = [(clock(K), K)]
-        while len(cands) < tries and free_b > (len(cands) + 1) * nbytes + (8 << 30):
-            if min(t for t, _ in cands) < 0.95 * max(t for t, _ in cands):
+        Ks = [K]
+        Ws = [backend.fresh_workspace(dev, ws_bytes)] if ws_bytes else [None]
+        took = {}
+
+        def time_new_pairs():
+            for i, Kc in enumerate(Ks):
+                for j, w in enumerate(Ws):
+                    if (i, j) not in took:
+                        if w is not None:
+                            backend.set_workspace(dev, "qfsym", w)
+                        took[(i, j)] = clock(Kc)
+
+        time_new_pairs()
+        while len(Ks) < tries and free_b > (len(Ks) + 1) * (nbytes + ws_bytes) + (8 << 30):
+            if min(took.values()) < 0.93 * max(took.values()):
                 break                                       # a fast and a slow placement have both been seen
-            Kn = build()
-            cands.append((clock(Kn), Kn))
-        times = [round(t, 4) for t, _ in cands]
-        best = min(range(len(cands)), key=lambda i: cands[i][0])
-        K = cands[best][1]
-        del cands
+            Ks.append(build())
+            if ws_bytes:
+                Ws.append(backend.fresh_workspace(dev, ws_bytes))
+            time_new_pairs()
+        bi, bj = min(took, key=took.get)
+        K = Ks[bi]
+        if Ws[bj] is not None:
+            backend.set_workspace(dev, "qfsym", Ws[bj])
+        self.gram_placement = {"contraction_ms_per_pair": [[i, j, round(t, 4)] for (i, j), t in sorted(took.items())],
+                               "kept": [bi, bj], "note": "[K_p copy, workspace, ms]"}
+        del Ks, Ws
         torch.cuda.empty_cache()
-        self.gram_placement = {"contraction_ms_per_try": times, "kept": best}
         return K
 
     def choose_overlap(self, reps=4):

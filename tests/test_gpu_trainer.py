@@ -267,8 +267,9 @@ def test_gram_placement_keeps_an_identical_matrix(dev):
     vi.gram_placement_tries = 3
     vi._prepare_stein(x)
     gp = vi.gram_placement
-    assert gp is not None and 1 <= len(gp["contraction_ms_per_try"]) <= vi.gram_placement_tries
-    assert gp["contraction_ms_per_try"][gp["kept"]] == min(gp["contraction_ms_per_try"])
+    pairs = gp["contraction_ms_per_pair"]
+    assert gp is not None and 1 <= len(pairs) <= vi.gram_placement_tries ** 2
+    assert [p for p in pairs if p[:2] == gp["kept"]][0][2] == min(p[2] for p in pairs)
     ref = backend.stein_gram(vi._S, n, vi.base_kernel_length_scale)
     assert torch.equal(vi._K, ref)
     vi.gram_placement_tries = 1
