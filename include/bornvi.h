@@ -168,7 +168,7 @@ int bornvi_stein_gram_build_rows(bornvi_handle h, int n, double length_scale, co
 
 /* Padded row pitch.  K_p with a power-of-two row pitch puts the same column of every row into the same HBM channel and
  * bank, and the symmetric contraction streams 32 rows per wave at the same column; bornvi_stein_gram_ld(n) is the
- * pitch (in doubles, >= 2^n, even) the library recommends: 2^n + 32 for n >= 12, else 2^n (n = 16: 2.56 ms on every
+ * pitch (in doubles, >= 2^n, even) the library recommends: 2^n + 32 for n >= 14, else 2^n (n = 16: 2.56 ms on every
  * allocation against 2.62 ... 2.83 ms dense; 0 for n outside [1, 17]).  The `_ld` entry points take any even pitch in
  * [2^n, 2^n + 4096]; columns >= 2^n of a row are never read or written. */
 long long bornvi_stein_gram_ld(int n);
@@ -193,7 +193,9 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
 
 /* Same result for a SYMMETRIC K (every K from bornvi_stein_gram_build is bitwise symmetric): reads
  * only the upper triangle, i.e. half the HBM traffic of bornvi_stein_quadform; deterministic (column
- * partials in the workspace instead of atomics).  q, y dev [2^n]; ksd2 dev [1]. */
+ * partials in the workspace instead of atomics).  q, y dev [2^n]; ksd2 dev [1].  A dense (unpadded) matrix with
+ * n < 14 is handed to the full-matrix kernel: too few 256-row bands to fill the chip, and the matrix is cache-sized
+ * (n = 12: 33 us against 93 us); same K q to rounding. */
 size_t bornvi_stein_quadform_sym_workspace_bytes(bornvi_handle h, int n);
 int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const double* q,
                               double* ksd2, double* y, void* workspace, size_t workspace_bytes,

@@ -318,7 +318,7 @@ def score_from_packed(packed, n, dev):
 
 def gram_ld(n):
     """Row pitch (doubles) the library recommends for a dense K_p that the symmetric contraction will stream:
-    2^n + 32 for n >= 12 (a power-of-two pitch makes the row streams of a band collide on one HBM channel: n = 16
+    2^n + 32 for n >= 14 (a power-of-two pitch makes the row streams of a band collide on one HBM channel: n = 16
     2.56 ms padded against 2.62 ... 2.83 ms dense, by allocation), else 2^n."""
     return int(_ext.lib().bornvi_stein_gram_ld(int(n)))
 

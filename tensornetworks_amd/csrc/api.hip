@@ -637,8 +637,9 @@ long long bornvi_stein_gram_ld(int n) {
   // matrices held at once, twice): pitch 2^n: 2.62 / 2.83 / 2.63 and 2.83 / 2.62 / 2.63 ms by allocation; pitch
   // 2^n + 32: 2.57 / 2.57 / 2.56 and 2.57 / 2.57 / 2.56 ms -- faster, and the dependence on where the matrix landed
   // is gone.  (With a power-of-two pitch the same column of every row maps to the same HBM channel and bank, and a wave
-  // streams 32 rows at the same column.)  Small matrices (a few MiB: cache-resident) stay dense.
-  return n >= 12 ? (1ll << n) + 32 : (1ll << n);
+  // streams 32 rows at the same column.)  Matrices below 2 GiB stay dense: the single-GPU contraction runs the
+  // full-matrix kernel on them (kernels_stein.hip: SYM_FULL_BELOW_N).
+  return n >= 14 ? (1ll << n) + 32 : (1ll << n);
 }
 
 int bornvi_stein_gram_build_rows_ld(bornvi_handle h, int n, double length_scale, const double* S, long long row_begin,

@@ -506,6 +506,11 @@ constexpr int SYM_BP = 512 / SYM_BAND;              // bands per 512-column trip
 constexpr int SYM_NEAR = 512;                       // per-wave capacity of near-diagonal column partials (< 480 used)
 constexpr int SYM_MAX_PARTS = 16;                   // column pieces per band (row-partial buffers in the workspace)
 constexpr int SYM_MIN_N = (SYM_WAVES == 4) ? 8 : 9; // smaller matrices (< 2 bands) go through the full-matrix kernel
+// A dense matrix below this size also takes the full-matrix kernel from the single-GPU entry point: with 2^n / 256 bands
+// there are too few workgroups to fill the chip, and the whole matrix is cache-sized.  Measured (tools/probes/
+// sym_vs_full_probe.py, band / full): n = 9: 41 / 24 us, 10: 69 / 24, 11: 90 / 24, 12: 93 / 33, 13: 110 / 86,
+// 14: 225 / 344, 15: 676 / 1270.  (The strip-pair shard of several GPUs keeps the band kernel.)
+constexpr int SYM_FULL_BELOW_N = 14;
 typedef double sym_d2 __attribute__((ext_vector_type(2)));
 typedef unsigned int sym_u4 __attribute__((ext_vector_type(4)));
 
@@ -730,10 +735,12 @@ __global__ __launch_bounds__(256) void quadform_sym_reduce_kernel(const double* 
 static long long sym_ws_partials(long long N) { return (((N + 63) / 64) + 31) / 32 * 32; }
 size_t quadform_sym_workspace_doubles(int n) {
   const long long N = 1ll << n;
-  if (n < SYM_MIN_N) return (size_t)quadform_partials(N) + 64;           // full-matrix kernel
+  const size_t full = (size_t)quadform_partials(N) + 64;                 // full-matrix kernel
+  if (n < SYM_MIN_N) return full;
   const long long nb = N / SYM_BAND;
   const long long z2 = sym_z2_offset(nb, N);
-  return (size_t)(SYM_MAX_PARTS * N) + (size_t)sym_ws_partials(N) + (size_t)(nb * SYM_WAVES * SYM_NEAR) + (size_t)(z2 > 0 ? z2 : 0) + 64;
+  const size_t band = (size_t)(SYM_MAX_PARTS * N) + (size_t)sym_ws_partials(N) + (size_t)(nb * SYM_WAVES * SYM_NEAR) + (size_t)(z2 > 0 ? z2 : 0) + 64;
+  return band > full ? band : full;
 }
 
 // pairs [pair_begin, pair_end) of the N / SYM_BAND / 2 band pairs; K_lo / K_hi as in quadform_sym_kernel.
@@ -772,10 +779,9 @@ hipError_t launch_quadform_sym_pairs(int n, const double* K_lo, const double* K_
 hipError_t launch_quadform_sym(int n, const double* K, long long ld, const double* q, double* y_or_null, double* ksd2,
                                double* ws, hipStream_t st) {
   const long long N = 1ll << n;
-  if (n < SYM_MIN_N) {                   // a few KiB: the full-matrix kernel (same result for a symmetric K)
-    if (ld != N) return hipErrorInvalidValue;
+  if (n < SYM_MIN_N && ld != N) return hipErrorInvalidValue;
+  if (n < SYM_MIN_N || (n < SYM_FULL_BELOW_N && ld == N))      // small: the full-matrix kernel (K is symmetric: same K q)
     return launch_quadform(n, K, 0, N, q, y_or_null, ksd2, ws, st);
-  }
   const long long nb = N / SYM_BAND;
   const long long npairs = (nb + 1) / 2;
   return launch_quadform_sym_pairs(n, K, K + (nb - npairs) * SYM_BAND * ld, ld, 0, npairs, q, y_or_null, ksd2, ws, st);

@@ -103,7 +103,7 @@ def test_quadform_and_kron_match_oracle(be, dev, n, seed):
     np.testing.assert_array_equal(k_only.cpu().numpy(), ksd2.cpu().numpy())
 
 
-@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_symmetric_quadform_equals_full(be, dev, n):
     """Upper-triangle contraction == full-matrix contraction (K_p is bitwise symmetric)."""
     bn, lat, obs, x = synthetic_network(n, 1)
@@ -120,12 +120,17 @@ def test_symmetric_quadform_equals_full(be, dev, n):
     # the reference value: dense NumPy product
     np.testing.assert_allclose(y_sym.cpu().numpy(), K.cpu().numpy() @ q.cpu().numpy(), rtol=0, atol=1e-13 * scale)
     if n >= 9:
-        # a padded row pitch (the [:, :2^n] view of a [2^n, 2^n + 32] buffer) holds the same matrix and contracts to the
-        # same bits; deterministic from call to call
+        # a padded row pitch (the [:, :2^n] view of a [2^n, 2^n + 32] buffer) holds the same matrix.  Below n = 14 a dense
+        # matrix takes the full-matrix kernel and a padded one the band kernel (two summation orders: equal to rounding);
+        # each is deterministic from call to call
         Kp = be.stein_gram(S, n, 1.0, ld=2 ** n + 32)
         assert Kp.stride(0) == 2 ** n + 32 and torch.equal(Kp, K)
         k_pad, y_pad = be.stein_quadform_sym(Kp, q, n)
-        assert torch.equal(y_pad, y_sym) and torch.equal(k_pad, k_sym)
+        assert (y_pad - y_sym).abs().max().item() <= 1e-13 * scale
+        assert abs(k_pad.item() - k_sym.item()) <= 1e-13 * float((q[:, None] * q[None, :] * K).abs().sum())
+        np.testing.assert_allclose(y_pad.cpu().numpy(), K.cpu().numpy() @ q.cpu().numpy(), rtol=0, atol=1e-13 * scale)
+        k_pad2, y_pad2 = be.stein_quadform_sym(Kp, q, n)
+        assert torch.equal(y_pad2, y_pad) and torch.equal(k_pad2, k_pad)
         k_again, y_again = be.stein_quadform_sym(K, q, n)
         assert torch.equal(y_again, y_sym) and torch.equal(k_again, k_sym)
 

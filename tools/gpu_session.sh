@@ -41,6 +41,7 @@ sym_trace() {   # which kernel carries the allocation-dependent time: main kerne
 ws_in_kp() { run 400 r2_ws_in_kp.log python tools/probes/ws_in_kp_probe.py; grep "^copy" gpurun_out/r2_ws_in_kp.log; FRONT=1 run 400 r2_ws_in_kp_front.log python tools/probes/ws_in_kp_probe.py; grep "^copy" gpurun_out/r2_ws_in_kp_front.log; }
 ws_far() { run 500 r2_ws_far.log python tools/probes/ws_far_probe.py; grep -A1 "^K_p" gpurun_out/r2_ws_far.log; }
 copy_far() { run 500 r2_copy_far.log python tools/probes/copy_far_probe.py; grep "^trial" gpurun_out/r2_copy_far.log; }
+sym_small() { run 300 r2_sym_small.log python tools/probes/sym_vs_full_probe.py; grep "^n=" gpurun_out/r2_sym_small.log; }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
 circ_ab() {
   run 300 r2_circ_ab_default.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_default.log
@@ -120,6 +121,15 @@ bench_place() {   # the headline step with 1 and with the default number of K_p 
     BORNVI_PLACEMENT_TRIES=$tries run 300 r2_bench_place_${tries}_$rep.log python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gate-bench --no-extras --series none
     grep '^{' gpurun_out/r2_bench_place_${tries}_$rep.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('tries $tries', r['value'], r['ms_per_step'], r['phase_ms']['circuits'], r['phase_ms']['stein'], r['precompute_seconds'], (r['gram_placement'] or {}).get('kept'))"
   done; done
+}
+small_libs() {   # the small graph-replayed workloads under every circuit-engine variant, same box
+  for rep in 1 2; do for lib in default tools/_variants/libbornvi_circ_*.so; do
+    v=$(basename $lib .so); unset BORNVI_LIB; [ $lib = default ] || export BORNVI_LIB=$PWD/$lib
+    for w in n8_L4_dense n12_L4_dense; do
+      run 300 r2_small_${v}_$w.log python bench.py --steps 200 --warmup 5 --workload $w --no-cpu-baseline --no-gate-bench --no-extras --series none
+      grep '^{' gpurun_out/r2_small_${v}_$w.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$v $w', r['value'], r['ms_per_step'])"
+    done
+  done; done; unset BORNVI_LIB
 }
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
