@@ -131,6 +131,8 @@ small_libs() {   # the small graph-replayed workloads under every circuit-engine
     done
   done; done; unset BORNVI_LIB
 }
+bench_overlap() { for o in -1 1 2; do run 300 r2_bench_overlap_$o.log python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gate-bench --no-extras --series none --overlap $o
+    grep '^{' gpurun_out/r2_bench_overlap_$o.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('overlap $o', r['value'], r['ms_per_step'], r['phase_ms']['circuits'], r['phase_ms']['stein'], r['overlap'])"; done; }
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
            run 300 r2_stream_probe_rand.log tools/_variants/stream_probe 3 0 1; cat gpurun_out/r2_stream_probe_rand.log; }
