@@ -163,7 +163,7 @@ void free_plan(DevPlan* dp) {
 size_t per_circuit_bytes(const Plan& p) {
   size_t b = (size_t)p.n_fused * 64;
   if (p.n_passes > 1) b += 2 * ((size_t)16 << p.n);
-  return b;
+  return b ? b : 64;      // (a circuit without gates -- `basic` with 0 layers -- needs nothing; callers divide by this)
 }
 
 // Runs all passes of `dp` for `bc` circuits.  in0: input state of pass 0 (or null for |0..0>);

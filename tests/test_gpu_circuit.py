@@ -79,6 +79,9 @@ def test_known_answers(be, dev):
 def test_zero_layers_and_large_batch(be, dev):
     q = gpu_probs(be, dev, "hardware_efficient", 4, 0, np.zeros((2, 0)))
     np.testing.assert_allclose(q, np.full((2, 16), 1 / 16), atol=1e-15)      # only the Hadamards
+    q = gpu_probs(be, dev, "basic", 5, 0, np.zeros((3, 0)))                  # no gate at all: |0..0> (found by
+    e0 = np.zeros(32); e0[0] = 1.0                                           # tests/test_gpu_properties.py: this divided by 0)
+    np.testing.assert_array_equal(q, np.tile(e0, (3, 1)))
     rng = np.random.default_rng(1)
     th = rng.uniform(-1, 1, (300, oc.num_params("basic", 7, 2)))
     q = gpu_probs(be, dev, "basic", 7, 2, th)
