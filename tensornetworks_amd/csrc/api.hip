@@ -258,9 +258,10 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
                   int shift_mode, int p_begin, int p_stride, int include_base, double* probs, void* ws, size_t ws_bytes,
                   hipStream_t st) {
   if (!h) return BORNVI_ERR_INVALID;
-  if (batch < 0 || (!thetas && num_params(ansatz, n, layers) > 0) || (!probs && batch > 0))
-    return fail(h, BORNVI_ERR_INVALID, "null pointer or negative batch");
-  if (batch == 0) return BORNVI_OK;
+  if (batch < 0) return fail(h, BORNVI_ERR_INVALID, "negative batch");
+  if (batch == 0) return BORNVI_OK;       // (an empty batch has no buffers: null pointers are fine)
+  if ((!thetas && num_params(ansatz, n, layers) > 0) || !probs)
+    return fail(h, BORNVI_ERR_INVALID, "null pointer");
   DevPlan* dp = nullptr;
   int rc = get_plan(h, ansatz, n, layers, &dp);
   if (rc) return rc;

@@ -82,6 +82,9 @@ def test_zero_layers_and_large_batch(be, dev):
     q = gpu_probs(be, dev, "basic", 5, 0, np.zeros((3, 0)))                  # no gate at all: |0..0> (found by
     e0 = np.zeros(32); e0[0] = 1.0                                           # tests/test_gpu_properties.py: this divided by 0)
     np.testing.assert_array_equal(q, np.tile(e0, (3, 1)))
+    # an empty batch is not an error (the buffers of an empty tensor are null pointers)
+    P = oc.num_params("all_to_all", 6, 2)
+    assert tuple(be.circuit_probs("all_to_all", 6, 2, torch.zeros((0, P), dtype=torch.float64, device=dev)).shape) == (0, 64)
     rng = np.random.default_rng(1)
     th = rng.uniform(-1, 1, (300, oc.num_params("basic", 7, 2)))
     q = gpu_probs(be, dev, "basic", 7, 2, th)
