@@ -511,19 +511,23 @@ def bench_adversarial(args, dev, D):
                                           classifier_config={}, device=str(dev))
     kw = dict(batch_size=batch, lr_born_machine=0.003, lr_classifier=0.03, k_classifier_steps=1, k_born_steps=1, verbose=False,
               adam_betas=(0.5, 0.999))
+    graph = None if args.graph < 0 else bool(args.graph)
     with contextlib.redirect_stdout(io.StringIO()):
-        adv.train(x, num_epochs=max(2, args.warmup), **kw)
+        adv.train(x, num_epochs=max(4, args.warmup), graph_epochs=graph, **kw)
         elapsed = []
         hist = None
-        adv.timers = {}
+        graphed = 0
         for _ in range(max(3, args.repeats)):
             D.barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            hist = adv.train(x, num_epochs=args.steps, **kw)
+            hist = adv.train(x, num_epochs=args.steps, graph_epochs=graph, **kw)
             torch.cuda.synchronize(dev)
             D.barrier()
             elapsed.append(D.max_over_ranks(time.perf_counter() - t0))
+            graphed = adv.graphed_epochs
+        adv.timers = {}                       # phase spans: a few eager epochs afterwards (no events inside a graph)
+        adv.train(x, num_epochs=max(4, args.steps // 2), graph_epochs=False, **kw)
     per = sorted(1e3 * e / args.steps for e in elapsed)
     med = float(np.median(per))
     P = adv.born_machine.num_ansatz_params
@@ -535,7 +539,10 @@ def bench_adversarial(args, dev, D):
                       "classifier": "BinaryClassifierMLP defaults (classifier_pytorch.py:27-41)",
                       "bayesian_network": f"synthetic n={n} seed=0, CPT entries U(0.25, 0.75)"},
            "repeats": {"n": len(per), "ms_per_step_median": round(med, 4), "ms_per_step_min": round(per[0], 4), "ms_per_step_max": round(per[-1], 4)},
-           "phase_ms": phase_means(adv.timers), "roofline": None, "cpu_baseline": None,
+           "launch": (f"{graphed} of {args.steps} epochs per call replayed from one HIP graph (the first two run eagerly and the "
+                      "third captures)" if graphed else "eager kernel launches") + (f"; capture failed: {adv.graph_error}" if adv.graph_error else ""),
+           "phase_ms": {**phase_means(adv.timers), "note": "event spans of eager epochs run after the timed region"},
+           "roofline": None, "cpu_baseline": None,
            "note": "torch-op composition around the HIP circuit engine (sampling, table gathers, MLP): no kernel of its own, "
                    "so no roofline row; the Born step's backward is 2P parameter-shift circuits",
            "loss_last": {"classifier": hist['loss_classifier'][-1], "born_machine": hist['loss_born_machine'][-1]}}

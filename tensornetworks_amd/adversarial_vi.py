@@ -158,13 +158,13 @@ class AdversarialVariationalInference:
                 idx = torch.multinomial(qd / qd.sum(), batch_size, replacement=True)
                 z_q = self._bits(idx.to(self.device))
                 logit_d = self.classifier(self._clf_inputs(z_q, x_obs_tensor, with_x)).squeeze()
-                log_p = self._log_p_table(x_obs_tensor)[idx.to(self.device)]
+                log_p = self._log_p_active[idx.to(self.device)]       # (the table of this observation, built by train())
                 raw_reward = logit_d - log_p
                 mean_reward = raw_reward.mean()
-                if first:
-                    self._baseline = mean_reward.clone()
+                if first:                                             # (in place: the tensor a captured epoch reads and writes)
+                    self._baseline.copy_(mean_reward)
                 else:
-                    self._baseline = baseline_decay * self._baseline + (1 - baseline_decay) * mean_reward
+                    self._baseline.mul_(baseline_decay).add_(mean_reward, alpha=1 - baseline_decay)
                 reinforce_reward = raw_reward - self._baseline
             log_q = torch.log(q.clamp(min=1e-9))[idx].to(self.device)
             loss_q = (log_q * reinforce_reward - (-0.01 * log_q)).mean()
@@ -174,7 +174,8 @@ class AdversarialVariationalInference:
             if fused_ok:
                 loss_q.backward()                                     # 2P parameter-shift circuits on the HIP engine
                 grad_norm_q = nn_utils.clip_grad_norm_(self.born_machine.parameters(), clip)
-                optimizer_born.found_inf = (~finite).to(torch.float32)     # skip the update on the device
+                self._found_inf.copy_((~finite).to(torch.float32))
+                optimizer_born.found_inf = self._found_inf                 # skip the update on the device
                 try:
                     optimizer_born.step()
                 finally:
@@ -190,11 +191,17 @@ class AdversarialVariationalInference:
     def train(self, x_observation_dict, num_epochs, batch_size, lr_born_machine, lr_classifier,
               k_classifier_steps=1, k_born_steps=1, verbose=True, true_posterior_for_tvd=None,
               use_lr_scheduler=True, gradient_clip_norm=10.0, baseline_decay=0.99,
-              optimizer_type="adam", adam_betas=(0.9, 0.999)):
+              optimizer_type="adam", adam_betas=(0.9, 0.999), *, graph_epochs=None):
         """Same signature, history keys and messages as the reference (adversarial_vi.py:104-270).  The epoch runs
         without host read-backs: losses and norms stay on the device and are fetched at the points where the reference
         prints (every num_epochs // 20 epochs) and once at the end; the "NaN or Inf" warning is therefore printed at
-        the next such point instead of inside the step."""
+        the next such point instead of inside the step.
+        graph_epochs (keyword-only extra; None = automatic: on the GPU with Adam, no event timers): after two eager
+        epochs the whole epoch body -- sampling, classifier forward / backward / Adam, the Born step with its 2P
+        parameter-shift circuits, the guard and its Adam step -- is captured ONCE into a HIP graph and replayed per epoch
+        (an epoch is ~150 small launches; at n = 12 it is bound by their host work).  Same operations in the same order;
+        the learning-rate schedulers advance on the host and fill the rate tensors the captured Adam kernels read.  If
+        the capture fails the epochs simply go on eagerly."""
         if self.num_observed_vars > 0 and set(x_observation_dict.keys()) != set(self.observed_vars_names):
             raise ValueError("Keys in x_observation_dict must match self.observed_vars_names.")
 
@@ -209,9 +216,16 @@ class AdversarialVariationalInference:
 
         on_gpu = torch.device(self.device).type == "cuda"
         fused = {"fused": True} if on_gpu else {}
+        want_graph = (graph_epochs if graph_epochs is not None else True) and on_gpu and optimizer_type == "adam" \
+            and self.timers is None and num_epochs > 3
         if optimizer_type == "adam":
-            optimizer_born = optim.Adam(self.born_machine.parameters(), lr=lr_born_machine, betas=adam_betas, **fused)
-            optimizer_classifier = optim.Adam(self.classifier.parameters(), lr=lr_classifier, betas=adam_betas, **fused)
+            lr_b, lr_c = lr_born_machine, lr_classifier
+            if want_graph:            # capturable Adam: step counter and learning rate live on the device
+                fused = {**fused, "capturable": True}
+                lr_b = torch.tensor(float(lr_born_machine), dtype=torch.float32, device=self.device)
+                lr_c = torch.tensor(float(lr_classifier), dtype=torch.float32, device=self.device)
+            optimizer_born = optim.Adam(self.born_machine.parameters(), lr=lr_b, betas=adam_betas, **fused)
+            optimizer_classifier = optim.Adam(self.classifier.parameters(), lr=lr_c, betas=adam_betas, **fused)
         else:
             optimizer_born = optim.SGD(self.born_machine.parameters(), lr=lr_born_machine, momentum=0.9, **fused)
             optimizer_classifier = optim.SGD(self.classifier.parameters(), lr=lr_classifier, momentum=0.9, **fused)
@@ -223,8 +237,10 @@ class AdversarialVariationalInference:
 
         criterion_classifier = nn.BCEWithLogitsLoss()
         self._baseline = torch.zeros((), device=self.device)
+        self._found_inf = torch.zeros((), dtype=torch.float32, device=self.device)
         self._label_cache = None
-        self._log_p_table(x_obs_tensor)                    # built once, outside the epochs
+        self._log_p_active = self._log_p_table(x_obs_tensor)   # built once, outside the epochs (its key is a host read-back)
+        self.graph_error = None
         dev_hist = {'loss_classifier': [], 'loss_born_machine': [], 'grad_norm_born': [], 'grad_norm_classifier': []}
         tvds = []
         best_tvd = float('inf')
@@ -240,22 +256,63 @@ class AdversarialVariationalInference:
         skipped = torch.zeros((), dtype=torch.int64, device=self.device)
         tvd_on_device = torch.is_tensor(true_posterior_for_tvd)
 
-        for epoch in range(num_epochs):
+        def epoch_body(first):
+            """(loss_d, grad_norm_d, loss_q [NaN where the update was skipped], grad_norm_q, number of skipped updates)"""
+            loss_d = grad_norm_d = None
             for _ in range(k_classifier_steps):
                 loss_d, grad_norm_d = self._classifier_step(batch_size, x_obs_tensor, with_x, optimizer_classifier,
                                                             criterion_classifier, gradient_clip_norm)
-            dev_hist['loss_classifier'].append(loss_d if loss_d is not None else nan_t)
-            dev_hist['grad_norm_classifier'].append(grad_norm_d.detach() if grad_norm_d is not None else zero_t)
-
             loss_q = grad_norm_q = finite = None
+            n_skip = torch.zeros((), dtype=torch.int64, device=self.device)
             for _ in range(k_born_steps):
                 loss_q, gn, finite = self._born_step(batch_size, x_obs_tensor, with_x, optimizer_born, gradient_clip_norm,
-                                                     baseline_decay, first=(epoch == 0))
+                                                     baseline_decay, first=first)
                 if gn is not None:
                     grad_norm_q = gn
-                skipped = skipped + (~finite).to(torch.int64)
-            dev_hist['loss_born_machine'].append(torch.where(finite, loss_q, nan_t.to(loss_q.dtype)) if loss_q is not None else nan_t)
-            dev_hist['grad_norm_born'].append(grad_norm_q.detach() if grad_norm_q is not None else zero_t)
+                n_skip = n_skip + (~finite).to(torch.int64)
+            return (loss_d if loss_d is not None else nan_t,
+                    grad_norm_d.detach() if grad_norm_d is not None else zero_t,
+                    torch.where(finite, loss_q, nan_t.to(loss_q.dtype)) if loss_q is not None else nan_t,
+                    grad_norm_q.detach() if grad_norm_q is not None else zero_t, n_skip)
+
+        graph = graph_out = side = None
+        self.graphed_epochs = 0             # epochs of this call replayed from the graph
+        for epoch in range(num_epochs):
+            if graph is not None:
+                graph.replay()
+                out = tuple(t.clone() for t in graph_out)           # the graph owns its outputs: keep copies
+                self.graphed_epochs += 1
+            elif want_graph and epoch in (1, 2):
+                try:
+                    dev_t = torch.device(self.device)
+                    if epoch == 1:          # an eager epoch on the capture stream: its workspaces exist before the capture
+                        side = torch.cuda.Stream(device=dev_t)
+                        side.wait_stream(torch.cuda.current_stream(dev_t))
+                        with torch.cuda.stream(side):
+                            out = epoch_body(False)
+                        torch.cuda.current_stream(dev_t).wait_stream(side)
+                    else:                   # capture the epoch body once, then run this epoch from the graph
+                        torch.cuda.synchronize(dev_t)
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=side):
+                            graph_out = epoch_body(False)
+                        g.replay()
+                        out = tuple(t.clone() for t in graph_out)
+                        graph = g
+                        self.graphed_epochs += 1
+                except Exception as e:      # not capturable on this set-up: the epochs go on eagerly
+                    want_graph = False
+                    graph = None
+                    self.graph_error = f"{type(e).__name__}: {e}"
+                    torch.cuda.synchronize()
+                    out = epoch_body(False)
+            else:
+                out = epoch_body(first=(epoch == 0))
+            dev_hist['loss_classifier'].append(out[0])
+            dev_hist['grad_norm_classifier'].append(out[1])
+            dev_hist['loss_born_machine'].append(out[2])
+            dev_hist['grad_norm_born'].append(out[3])
+            skipped = skipped + out[4]
 
             if scheduler_born is not None:
                 scheduler_born.step()

@@ -93,7 +93,7 @@ profile() {
   tools/pmc_traffic.sh 2>&1 | tail -3
 }
 tests_advq() { run 600 r2_gpu_tests_adv.log python -m pytest tests/test_gpu_adversarial.py -m gpu -x -q; tail -n 25 gpurun_out/r2_gpu_tests_adv.log; }
-bench_adv() { run 300 r2_bench_adv.log python bench.py --steps 20 --warmup 3 --workload adv_n12_b65536; grep '^{' gpurun_out/r2_bench_adv.log > gpurun_out/r2_bench_adv.json; tail -c 1500 gpurun_out/r2_bench_adv.json; }
+bench_adv() { run 300 r2_bench_adv.log python bench.py --steps ${ADV_STEPS:-200} --warmup 3 --workload adv_n12_b65536; grep '^{' gpurun_out/r2_bench_adv.log > gpurun_out/r2_bench_adv.json; tail -c 1500 gpurun_out/r2_bench_adv.json; }
 tests_graph() { run 600 r2_gpu_tests_graph.log python -m pytest tests/test_gpu_trainer.py -m gpu -x -q -k "graphed or async"; tail -n 25 gpurun_out/r2_gpu_tests_graph.log; }
 bench_small() { for w in n8_L4_dense n12_L4_dense; do run 300 r2_bench_$w.log python bench.py --steps 200 --warmup 5 --workload $w --no-cpu-baseline --no-gate-bench --series none; grep '^{' gpurun_out/r2_bench_$w.log > gpurun_out/r2_bench_$w.json; python -c "
 import json; r=json.load(open('gpurun_out/r2_bench_$w.json')); print('$w', r['value'], 'steps/s', r['ms_per_step'], 'ms', r['launch'], r['extras']['adjoint_engine'])"; done; }
