@@ -190,7 +190,19 @@ class KSDVariationalInference:
         builds and keeps only its block of N/W rows of K_p (row shard of the quadratic form)."""
         dev = backend.compute_device(self.pytorch_device)
         n = self.num_latent_vars
-        self._S = score_matrix(self.bn, x_dict, self.latent_vars_names, device=dev)
+        S_new = score_matrix(self.bn, x_dict, self.latent_vars_names, device=dev)
+        # K_p is a function of (S, n, length scale) only: a second train() on the same observation and network keeps the
+        # matrix it has (32 GiB and a placement search at n = 16) -- the scores themselves are recomputed like the
+        # reference does (one launch)
+        sig = (float(self.base_kernel_length_scale), self._use_dense(), bool(self.symmetric_contraction),
+               shard.world(self.process_group), int(self.gram_placement_tries))
+        if (self._use_dense() and getattr(self, "_K", None) is not None and getattr(self, "_K_sig", None) == sig
+                and self._S is not None and self._S.shape == S_new.shape and torch.equal(self._S, S_new)):
+            self._S = S_new
+            self._stein_key = self._key(x_dict)
+            return
+        self._S = S_new
+        self._K_sig = sig
         self._K = None
         self._K_rows = None
         self._K_pairs = None
@@ -514,7 +526,7 @@ class KSDVariationalInference:
             scheduler.step()
         return loss_t, grad_norm, q
 
-    def make_graphed_step(self, params, optimizer_born, scheduler, gradient_clip_norm, warmup=3):
+    def make_graphed_step(self, params, optimizer_born, scheduler, gradient_clip_norm, warmup=3, record=None):
         """The epoch body of `training_step_async` captured ONCE into a HIP graph (torch.cuda.CUDAGraph: our kernels
         are launched on torch's current stream, so the capture records them together with the cast, the fused Adam
         kernel and the guard) and replayed per step: one graph launch instead of ~15 kernel launches and their host
@@ -549,7 +561,9 @@ class KSDVariationalInference:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(1, int(warmup))):      # plans, workspaces and optimiser state exist before the capture
-                body()
+                w = body()                            # (real optimiser steps: `record`, a list, receives their outputs)
+                if record is not None:
+                    record.append(tuple(t.clone() for t in w))
                 if scheduler is not None:
                     scheduler.step()
         torch.cuda.current_stream(dev).wait_stream(side)
@@ -591,7 +605,16 @@ class KSDVariationalInference:
     def train(self, x_observation_dict, num_epochs, lr_born_machine,
               verbose=True, true_posterior_for_tvd=None,
               use_lr_scheduler=True, gradient_clip_norm=10.0,
-              optimizer_type="adam", adam_betas=(0.9, 0.999)):
+              optimizer_type="adam", adam_betas=(0.9, 0.999), *, host_sync=True):
+        """Same signature, history keys and messages as the reference (ksd_vi_quantum.py:76-190).
+        host_sync (keyword-only extra): True = the reference's epoch, which reads `loss.item()` every epoch.  False =
+        the same epochs without host synchronisation (theta on the GPU): `training_step_async` per epoch -- for
+        n <= 13 with Adam replayed from ONE HIP graph (`make_graphed_step`) -- with the NaN/Inf guard on the device; losses,
+        norms and TVDs stay on the device and are read where the reference prints and once at the end, so a "Skipping
+        update" warning appears at the next such point.  Same history."""
+        if not host_sync:
+            return self._train_deferred(x_observation_dict, num_epochs, lr_born_machine, verbose, true_posterior_for_tvd,
+                                        use_lr_scheduler, gradient_clip_norm, optimizer_type, adam_betas)
 
         if self.num_observed_vars > 0 and set(x_observation_dict.keys()) != set(self.observed_vars_names):
             raise ValueError("Keys in x_observation_dict must match self.observed_vars_names.")
@@ -661,4 +684,88 @@ class KSDVariationalInference:
             print(f"\nRestoring best parameters (TVD: {best_tvd:.6f})")
             self.born_machine.load_state_dict(best_params)
 
+        return history
+
+    def _train_deferred(self, x_observation_dict, num_epochs, lr_born_machine, verbose, true_posterior_for_tvd,
+                        use_lr_scheduler, gradient_clip_norm, optimizer_type, adam_betas):
+        """train(host_sync=False): see there.  The epochs are `training_step_async` (or its HIP-graph replay)."""
+        if self.num_observed_vars > 0 and set(x_observation_dict.keys()) != set(self.observed_vars_names):
+            raise ValueError("Keys in x_observation_dict must match self.observed_vars_names.")
+        theta = self.born_machine.theta
+        if not (theta.is_cuda and theta.dtype == torch.float32):
+            raise backend.BornviError("train(host_sync=False) needs a float32 theta on the GPU (pytorch_device='cuda:N')")
+        self._precompute_all_s_p(x_observation_dict)
+        n = self.num_latent_vars
+        rank, ws = shard.world(self.process_group)
+        use_graph = (optimizer_type == "adam" and n <= 13 and ws == 1 and self.timers is None and num_epochs > 4
+                     and not self.overlap_streams and true_posterior_for_tvd is None)   # (a TVD per epoch needs theta
+                                                                                          # after exactly that epoch)
+        params, optimizer_born, scheduler = self.make_optimizer(lr_born_machine, num_epochs, use_lr_scheduler,
+                                                                optimizer_type, adam_betas, capturable=use_graph)
+        dev = theta.device
+        losses, norms, tvds, first4 = [], [], [], {}
+        log_every = (num_epochs // 10 if num_epochs >= 10 else 1)
+        tvd_table_dev = None
+        if true_posterior_for_tvd is not None:
+            tvd_table_dev = (true_posterior_for_tvd if torch.is_tensor(true_posterior_for_tvd)
+                             else torch.tensor([true_posterior_for_tvd.get(o, 0.0) for o in self.all_latent_states_tuples],
+                                               dtype=torch.float64)).to(self._S.device)
+        step = None
+        seen = 0                              # epochs whose warnings / values have been reported
+
+        def report(upto):
+            nonlocal seen
+            if upto <= seen:
+                return None
+            vals = torch.stack([l.reshape(()) for l in losses[seen:upto]]).cpu().tolist()
+            for v in vals:
+                if np.isnan(v) or np.isinf(v):
+                    print(f"Warning: NaN or Inf KSD loss: {v}. Skipping update.")
+            seen = upto
+            return vals[-1]
+
+        for epoch in range(num_epochs):
+            if use_graph and epoch == 0:
+                rec = []
+                step = self.make_graphed_step(params, optimizer_born, scheduler, gradient_clip_norm, warmup=2, record=rec)
+                pending = rec                 # epochs 0 and 1 are the graph's two eager warm-up steps
+            if use_graph and epoch < 2:
+                loss_t, gn, q = pending[epoch]
+            elif use_graph:
+                loss_t, gn, q = (t.clone() for t in step())
+            else:
+                loss_t, gn, q = self.training_step_async(params, optimizer_born, scheduler, gradient_clip_norm)
+            if q.shape[0] != self.num_possible_latent_states:
+                raise ValueError(f"Probabilities from Born machine have unexpected shape")
+            losses.append(loss_t)
+            norms.append(gn)
+            if tvd_table_dev is not None:     # like the reference: the distribution AFTER this epoch's update (:168)
+                q_now = self.born_machine.get_probabilities().detach().squeeze()
+                tvds.append(tvd_table(tvd_table_dev.to(q_now.device), q_now))
+            if verbose and epoch % log_every == 0:
+                print(f"  Epoch {epoch+1} Q Probs (first 4): {q[:4].detach().cpu().numpy()}")
+                report(epoch + 1)
+                print(f"  Epoch {epoch+1} Grad Norm (after clipping): {float(gn):.4f}")
+            if verbose and (epoch % max(1, num_epochs // 20) == 0 or epoch == num_epochs - 1):
+                last = report(epoch + 1)
+                last = float(losses[-1]) if last is None else last
+                log_msg = f"Epoch {epoch+1}/{num_epochs} | KSD: {last:.6f}"
+                if scheduler is not None:
+                    log_msg += f" | LR: {float(scheduler.get_last_lr()[0]):.6f}"
+                if tvds:
+                    log_msg += f" | TVD: {float(tvds[-1]):.6f}"
+                print(log_msg)
+        report(num_epochs)
+        loss_h = torch.stack([l.reshape(()) for l in losses]).cpu().tolist() if losses else []
+        norm_h = torch.stack([g.reshape(()).to(torch.float64) for g in norms]).cpu().tolist() if norms else []
+        # the reference keeps the last good norm on a skipped epoch (0.0 before the first good one)
+        grad_h, last_good = [], None
+        for lv, gv in zip(loss_h, norm_h):
+            if not (np.isnan(lv) or np.isinf(lv)):
+                last_good = gv
+            grad_h.append(last_good if last_good is not None else 0.0)
+        tvd_h = (torch.stack([t.reshape(()) for t in tvds]).cpu().tolist() if tvds else [np.nan] * num_epochs)
+        history = {'loss_ksd': loss_h, 'tvd': tvd_h, 'grad_norm': grad_h}
+        if tvds and verbose:
+            print(f"\nRestoring best parameters (TVD: {min(tvd_h):.6f})")     # (a no-op in the reference too: quirk Q3)
         return history

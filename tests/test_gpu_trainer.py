@@ -330,3 +330,59 @@ def test_graphed_step_replays_the_async_step(dev):
         vi2._prepare_stein(x)
         p2, o2, s2 = vi2.make_optimizer(0.01, 9, True, "adam", (0.9, 0.999))        # not capturable
         vi2.make_graphed_step(p2, o2, s2, 10.0)
+
+
+@pytest.mark.parametrize("n,L,opt,with_tvd", [(3, 2, "adam", True), (3, 2, "sgd", False), (8, 2, "adam", False), (8, 1, "adam", True)])
+def test_train_without_host_sync_returns_the_same_history(dev, n, L, opt, with_tvd, capsys):
+    """train(host_sync=False): the reference's epochs without the per-epoch loss.item() -- training_step_async, or for
+    n <= 13 with Adam and no per-epoch TVD its HIP-graph replay -- and the values read back at the log points.  Same
+    history as train() (the graph path uses torch's capturable Adam: equal to rounding), same final theta, same log lines."""
+    from tensornetworks_amd import stein_utils
+    if n == 3:
+        bn, lat, obs, x = get_sprinkler_network(False), ['C', 'S', 'R'], ['W'], {'W': 1}
+    else:
+        bn, lat, obs, x = synthetic_network(n, 5)
+    runs = []
+    for host_sync in (True, False):
+        vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=3, gram_mode="dense")
+        post = stein_utils.true_posterior_table(bn, x, lat, dev)[0] if with_tvd else None
+        h = vi.train(x, 12, 0.05, verbose=True, true_posterior_for_tvd=post, optimizer_type=opt, host_sync=host_sync)
+        out = capsys.readouterr().out
+        runs.append((h, vi.born_machine.theta.detach().cpu().numpy().copy(), [l for l in out.splitlines() if l.startswith("Epoch ")]))
+    (h0, t0, log0), (h1, t1, log1) = runs
+    assert len(h1["loss_ksd"]) == 12 and len(h1["grad_norm"]) == 12 and len(h1["tvd"]) == 12
+    np.testing.assert_allclose(h1["loss_ksd"], h0["loss_ksd"], rtol=2e-5)
+    np.testing.assert_allclose(h1["grad_norm"], [float(g) for g in h0["grad_norm"]], rtol=2e-4)
+    np.testing.assert_allclose(t1, t0, rtol=0, atol=2e-5)
+    if with_tvd:
+        np.testing.assert_allclose(h1["tvd"], h0["tvd"], rtol=0, atol=1e-5)
+    else:
+        assert all(np.isnan(v) for v in h1["tvd"])
+    assert len(log1) == len(log0) and all(a.split(" | ")[0] == b.split(" | ")[0] for a, b in zip(log0, log1))
+    assert h1["loss_ksd"][-1] < h1["loss_ksd"][0]
+
+
+def test_second_train_keeps_the_gram_matrix_unless_the_scores_change(dev, capsys):
+    """K_p depends on (S, n, length scale) only: a second _prepare_stein / train() on the same observation keeps the matrix
+    (at n = 16 that is 32 GiB and a placement search); another observation, length scale or contraction layout rebuilds."""
+    n = 9
+    bn, lat, obs, x = synthetic_network(n, 4)
+    vi = make_vi(bn, lat, obs, n, 1, "basic", "cuda:0", gram_mode="dense")
+    vi._prepare_stein(x)
+    K0, ptr0 = vi._K, vi._K.data_ptr()
+    vi.train(x, 2, 0.01, verbose=False)
+    assert vi._K.data_ptr() == ptr0                       # same observation: kept
+    x2 = {k: 1 - v for k, v in x.items()}
+    vi._prepare_stein(x2)
+    assert not torch.equal(vi._K, K0)                     # other observation: other scores, rebuilt
+    vi._prepare_stein(x)
+    assert torch.equal(vi._K, K0)
+    ptr1 = vi._K.data_ptr()
+    vi.base_kernel_length_scale = 2.0
+    vi._prepare_stein(x)
+    assert not torch.equal(vi._K, K0)
+    vi.base_kernel_length_scale = 1.0
+    vi.symmetric_contraction = False
+    vi._prepare_stein(x)
+    assert torch.equal(vi._K, K0)
+    capsys.readouterr()
