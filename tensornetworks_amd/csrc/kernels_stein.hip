@@ -493,6 +493,9 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
 #ifndef BORNVI_SYM_ABLATE      // timing-only builds (tools/probes): 2 = no column part at all (results invalid)
 #define BORNVI_SYM_ABLATE 0
 #endif
+#ifndef BORNVI_SYM_STORE_NT
+#define BORNVI_SYM_STORE_NT 0      // 1: the column-partial stores non-temporal (A/B)
+#endif
 #ifndef BORNVI_SYM_DEFER_STORE
 #define BORNVI_SYM_DEFER_STORE 1   // 0: store a trip's column partial at once (A/B)
 #endif
@@ -560,7 +563,13 @@ __device__ __forceinline__ void sym_trip(__amdgpu_buffer_rsrc_t rsrc, long long 
     for (int u = 0; u < RB; ++u)
 #pragma unroll
       for (int c = 0; c < CH; ++c) kv[u][c] = sym_load16(rsrc, vlane, soff[c] + (unsigned)(r0 + u) * ld8);
-    if (PEND && r0 == 0) *pend_ptr = pend;
+    if (PEND && r0 == 0) {
+#if BORNVI_SYM_STORE_NT
+      __builtin_nontemporal_store(pend, pend_ptr);
+#else
+      *pend_ptr = pend;
+#endif
+    }
 #pragma unroll
     for (int u = 0; u < RB; ++u)
 #pragma unroll
@@ -639,7 +648,13 @@ __device__ __forceinline__ void quadform_sym_band(const double* __restrict__ Kb 
       }
     }
   }
-  if (DEFER && t1 > t0) *pend_ptr = pend;
+  if (DEFER && t1 > t0) {
+#if BORNVI_SYM_STORE_NT
+    __builtin_nontemporal_store(pend, pend_ptr);
+#else
+    *pend_ptr = pend;
+#endif
+  }
   __syncthreads();      // the LDS buffers are reused by the next band of this workgroup
 #pragma unroll
   for (int r = 0; r < SYM_ROWS; ++r) {

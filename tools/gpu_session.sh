@@ -42,6 +42,7 @@ ws_in_kp() { run 400 r2_ws_in_kp.log python tools/probes/ws_in_kp_probe.py; grep
 ws_far() { run 500 r2_ws_far.log python tools/probes/ws_far_probe.py; grep -A1 "^K_p" gpurun_out/r2_ws_far.log; }
 copy_far() { run 500 r2_copy_far.log python tools/probes/copy_far_probe.py; grep "^trial" gpurun_out/r2_copy_far.log; }
 sym_small() { run 300 r2_sym_small.log python tools/probes/sym_vs_full_probe.py; grep "^n=" gpurun_out/r2_sym_small.log; }
+uncached() { run 500 r2_uncached.log python tools/probes/uncached_kp_probe.py; grep "ms per\|failed" gpurun_out/r2_uncached.log; }
 chunks() { run 600 r2_chunk_probe.log python tools/probes/chunk_stream_probe.py; grep -v amdgpu.ids gpurun_out/r2_chunk_probe.log | tail -14; }
 circ_ab() {
   run 300 r2_circ_ab_default.log python tools/probes/circuit_ab.py; grep "n=" gpurun_out/r2_circ_ab_default.log
