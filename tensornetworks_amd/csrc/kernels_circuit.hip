@@ -498,6 +498,14 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // a large-tile workgroup reach the end of a stage together; 16 ds_write_b128 per wave issued in one burst by all of
 // them kept the LDS write path (~80 B/clk/CU) busy for ~1600 cycles per stage with the VALU idle.  Same operations on
 // the same values: bit-identical results.
+#ifndef BORNVI_GATE_PRIO
+#define BORNVI_GATE_PRIO 0       // experiment: s_setprio level while a wave runs its gates (0 = off)
+#endif
+#if BORNVI_GATE_PRIO
+#define BORNVI_PRIO_OFF() __builtin_amdgcn_s_setprio(0)
+#else
+#define BORNVI_PRIO_OFF() do { } while (0)
+#endif
 #ifndef BORNVI_EARLY_WRITE
 #define BORNVI_EARLY_WRITE 1     // large-tile instantiation only (LT below); 0: round-1 stage body everywhere (A/B)
 #endif
@@ -646,6 +654,9 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
     }
   }
   if (PRE) apply_sign_bits(my_sg & 0xffffu, ar, ai);
+#if BORNVI_GATE_PRIO
+  if (LT && NG > 0) __builtin_amdgcn_s_setprio(BORNVI_GATE_PRIO);   // experiment: the wave inside its gates wins the issue arbitration
+#endif
   if (BORNVI_EARLY_WRITE && LT && !DEBUG && NG > 0 && (IO != 2 || BORNVI_EARLY_STORE)) {
     constexpr int LAST = NG > 0 ? NG - 1 : 0;
     uint32_t wa0 = (IO == 2) ? hbm_off : (my_rw >> 16) << 4;
@@ -655,6 +666,7 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
       asm volatile("" : "+v"(wa0));   /* the write base is formed here, before the last gate */                \
       if (IO == 2) op_u1_last_and_store<LAST, POST>(ar, ai, U_, my_sg >> 16, wa0, hbm_basis, hbm_base, fin);   \
       else op_u1_last_and_write<LAST, POST>(ar, ai, U_, my_sg >> 16, tile, wa0, G);                            \
+      BORNVI_PRIO_OFF();                                                                                        \
     } while (0)
 #if BORNVI_U_PREFETCH
     // two matrix register sets: the next gate's four broadcast LDS reads are in flight under the current gate's FMAs
