@@ -324,6 +324,11 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
           }
         }
       }
+#pragma unroll
+      for (int p2 = 0; p2 < 16; ++p2) {        // phase-0 CNOTs whose target is a thread-held position (plan.hpp: BpreF)
+        const uint32_t m = G[48 + p2];
+        if (m) lflip ^= (__popc(e & m) & 1) ? lds_swizzle(1u << p2) : 0u;
+      }
       const int nreg = 1 << r;
       const uint32_t rbase = pb ^ lflip, wbase = pb ^ sflip;
       double ar[16], ai[16];

@@ -196,7 +196,10 @@ void stage_select(const std::vector<Op>& ops, const std::vector<int>& pool, int 
       if (ph < 0) blk = true;
     }
     const int t = op_target(o);
-    if (!blk && t >= 0 && !in_t[t]) {
+    // (a phase-0 CNOT is folded into the stage's READ map, which may move any local bit: its target need not be one of
+    // the `cap` register wires -- only a fused U and a phase-3 CNOT, whose write-back must stay inside the thread's own
+    // group, claim one)
+    if (!blk && t >= 0 && !in_t[t] && !(o.kind == K_CX && ph == 0)) {
       if ((int)S.targets.size() < cap) { in_t[t] = 1; S.targets.push_back(t); }
       else blk = true;
     }
@@ -689,12 +692,30 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
         }
       };
       Expr pre[4], post[4];
-      compose(sel.pre_cx, true, pre);     // inverse map: where the amplitude of slot j is read from
       compose(sel.post_cx, false, post);  // forward map: where the amplitude of slot j is written to
+      // READ map (phase-0 CNOTs, inverse = the same CNOTs in reverse order) over ALL k LDS positions: source bit of
+      // position p = parity(areg & slot) ^ parity(bext & e).  Register positions start as (1 << t, 0), thread-held
+      // positions as (0, 1 << p), workgroup bits never change.
+      std::vector<Expr> pre_pos((size_t)k);
+      for (int p2 = 0; p2 < k; ++p2) pre_pos[(size_t)p2] = Expr{0u, 1u << p2};
+      for (int t = 0; t < r; ++t) pre_pos[(size_t)ldspos[regw[t]]] = Expr{1u << t, 0u};
+      for (size_t q = 0; q < sel.pre_cx.size(); ++q) {
+        const Op& o = ops[sel.pre_cx[sel.pre_cx.size() - 1 - q]];
+        const Expr ce = ldspos[o.a] >= 0 ? pre_pos[(size_t)ldspos[o.a]] : Expr{0u, 1u << extpos(o.a)};
+        Expr& te = pre_pos[(size_t)ldspos[o.b]];
+        te.areg ^= ce.areg; te.bext ^= ce.bext;
+      }
+      for (int t = 0; t < 4; ++t) pre[t] = t < r ? pre_pos[(size_t)ldspos[regw[t]]] : Expr{1u << t, 0u};
       auto slot_offset = [&](const Expr (&ex)[4], int j) {
         uint32_t off = 0;
         for (int t = 0; t < r; ++t)
           if (__builtin_popcount(ex[t].areg & (uint32_t)j) & 1) off |= 1u << ldspos[regw[t]];
+        return off;
+      };
+      auto read_slot_offset = [&](int j) {      // all positions: a read may come from another thread's group
+        uint32_t off = 0;
+        for (int p2 = 0; p2 < k; ++p2)
+          if (__builtin_popcount(pre_pos[(size_t)p2].areg & (uint32_t)j) & 1) off |= 1u << p2;
         return off;
       };
       auto emit_signq = [&](const std::vector<int>& czs, const Expr (&ex)[4]) {
@@ -731,9 +752,11 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
       W[base + PW_MATS + 2 * nstages + 1] = W[sbase + 7];
       for (int t = 0; t < 4; ++t) { W[sbase + 8 + t] = t < r ? pre[t].bext : 0u; W[sbase + 12 + t] = t < r ? post[t].bext : 0u; }
       for (int j = 0; j < 16; ++j) {
-        W[sbase + 16 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(pre, j)) : 0u;
+        W[sbase + 16 + j] = (j < (1 << r)) ? lds_swizzle(read_slot_offset(j)) : 0u;
         W[sbase + 32 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(post, j)) : 0u;
       }
+      for (int p2 = 0; p2 < k; ++p2)          // thread-held positions moved by the read map
+        if (!isr[P.lds_wire[p2]]) W[sbase + 48 + p2] = pre_pos[(size_t)p2].bext ^ (1u << p2);
       uint32_t flags = io_flags;
       Expr ident[4];
       for (int t = 0; t < 4; ++t) ident[t] = Expr{1u << t, 0u};
@@ -870,6 +893,8 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
             if (parity(e & S[8 + b])) lflip ^= sri[b];
             if (parity(e & S[12 + b])) { sflip ^= sri[b]; e2 |= 1u << rpos[b]; }
           }
+          for (int p2 = 0; p2 < k; ++p2)
+            if (S[48 + p2] && parity(e & S[48 + p2])) lflip ^= lds_swizzle(1u << p2);
           RW[((size_t)g << kt) + t] = (pb ^ lflip) | ((pb ^ sflip) << 16);
           if (SG) SG[((size_t)g << kt) + t] = (Qpre ? sign_bits(Qpre, e) : 0u) | ((Qpost ? sign_bits(Qpost, e2) : 0u) << 16);
         }

@@ -94,10 +94,12 @@ constexpr uint32_t PASS_FINAL_STATE = 4u;  // epilogue writes the state itself i
 //   [12..15] Bpost[t]: same for the LDS WRITE index        (e = extended index: LDS bits, then workgroup bits)
 //   [16..31] load_off[16]:  swizzled LDS offset register slot j is read from
 //   [32..47] store_off[16]: swizzled LDS offset register slot j is written to
+//   [48..63] BpreF[p]: parity(e & BpreF[p]) flips LDS bit p of the READ index (p not a register position): phase-0 CNOTs
+//            whose target is a thread-held wire -- a GF(2)-linear read map costs nothing whichever bits it moves
 //   then SIGNQ_WORDS words if STAGE_SIGN_PRE, then SIGNQ_WORDS words if STAGE_SIGN_POST,
 //   then 2^(k-r) words: thread t's  lds_swizzle(base_t) | base_t << 16  (base_t = t's bits deposited at the
 //   non-register LDS positions) -- index arithmetic done once by the planner instead of per stage per thread
-constexpr int STAGE_HDR_WORDS = 48;
+constexpr int STAGE_HDR_WORDS = 64;
 constexpr uint32_t STAGE_SIGN_PRE = 1u;
 constexpr uint32_t STAGE_SIGN_POST = 2u;
 // thread-bit order of the stage allows the fast kernel to take the stage's amplitudes straight from HBM (first

