@@ -1,5 +1,7 @@
 // Circuit execution planner -- see plan.hpp for the model.
 #include "plan.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <array>
@@ -179,8 +181,10 @@ struct StageSel {
   size_t count() const { return pre_cx.size() + pre_cz.size() + us.size() + post_cx.size() + post_cz.size(); }
 };
 
+// defer_cx3: a CNOT that could only run in phase 3 AND would claim a new register wire is left for the next stage,
+// where it is a phase-0 CNOT (folded into the read map: free) -- the register wires then go to fused U's.
 void stage_select(const std::vector<Op>& ops, const std::vector<int>& pool, int n, int cap, StageSel& S,
-                  std::vector<int>& rest) {
+                  std::vector<int>& rest, bool defer_cx3 = false) {
   std::vector<char> blocked(n, 0), in_t(n, 0), has_u(n, 0);
   std::vector<int> wphase(n, 0);
   rest.clear();
@@ -200,7 +204,8 @@ void stage_select(const std::vector<Op>& ops, const std::vector<int>& pool, int 
     // the `cap` register wires -- only a fused U and a phase-3 CNOT, whose write-back must stay inside the thread's own
     // group, claim one)
     if (!blk && t >= 0 && !in_t[t] && !(o.kind == K_CX && ph == 0)) {
-      if ((int)S.targets.size() < cap) { in_t[t] = 1; S.targets.push_back(t); }
+      if (defer_cx3 && o.kind == K_CX) blk = true;
+      else if ((int)S.targets.size() < cap) { in_t[t] = 1; S.targets.push_back(t); }
       else blk = true;
     }
     if (blk) {
@@ -275,6 +280,24 @@ void split_pass_ops(const std::vector<Op>& ops, const std::vector<int>& pass_ops
 }
 
 // target wires of the first and of the last stage of a pass (they depend on the ops only, not on the layout)
+// number of stages the core ops of a pass need under a stage-selection policy
+int count_stages(const std::vector<Op>& ops, const std::vector<int>& core, int n, int r, bool defer_cx3) {
+  std::vector<int> pool = core, rest;
+  int cnt = 0;
+  while (!pool.empty()) {
+    StageSel sel;
+    stage_select(ops, pool, n, r, sel, rest, defer_cx3);
+    if (sel.count() == 0) return 1 << 20;
+    ++cnt;
+    pool = rest;
+  }
+  return cnt;
+}
+// the policy with fewer stages (ties: the program-order greedy one)
+bool pick_defer_policy(const std::vector<Op>& ops, const std::vector<int>& core, int n, int r) {
+  return count_stages(ops, core, n, r, true) < count_stages(ops, core, n, r, false);
+}
+
 void first_last_stage_targets(const std::vector<Op>& ops, const std::vector<int>& pass_ops, int n, int r, bool is_init,
                               std::vector<int>& first_t, std::vector<int>& last_t) {
   std::vector<int> lead, core, trail, rest;
@@ -282,9 +305,10 @@ void first_last_stage_targets(const std::vector<Op>& ops, const std::vector<int>
   first_t.clear(); last_t.clear();
   std::vector<int> pool = core;
   bool first = true;
+  const bool defer = pick_defer_policy(ops, core, n, r);
   while (!pool.empty()) {
     StageSel sel;
-    stage_select(ops, pool, n, r, sel, rest);
+    stage_select(ops, pool, n, r, sel, rest, defer);
     if (sel.count() == 0) break;
     if (first) { first_t = sel.targets; first = false; }
     last_t = sel.targets;
@@ -618,10 +642,22 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     //      the 2^r-element group a thread owns, so the in-place write-back needs no extra barrier.
     std::vector<int> pool = core, rest;
     uint32_t nstages = 0;
+    const bool defer_cx3 = pick_defer_policy(ops, core, n, r);
     while (!pool.empty()) {
       StageSel sel;
-      stage_select(ops, pool, n, r, sel, rest);
+      stage_select(ops, pool, n, r, sel, rest, defer_cx3);
       if (sel.count() == 0) { msg = "stage planner made no progress"; return false; }
+      if (getenv("BORNVI_PLAN_DEBUG")) {
+        auto show = [&](const char* nm, const std::vector<int>& v) {
+          fprintf(stderr, " %s[", nm);
+          for (int idx : v) fprintf(stderr, "%s%d%s ", ops[idx].kind == K_U1 ? "U" : (ops[idx].kind == K_CX ? "X" : "Z"), ops[idx].a,
+                                    ops[idx].b >= 0 ? (std::string(">") + std::to_string(ops[idx].b)).c_str() : "");
+          fprintf(stderr, "]");
+        };
+        fprintf(stderr, "pass %d stage %u:", i, nstages);
+        show("cx0", sel.pre_cx); show("cz1", sel.pre_cz); show("u", sel.us); show("cx3", sel.post_cx); show("cz4", sel.post_cz);
+        fprintf(stderr, "  rest %zu\n", rest.size());
+      }
       // register wires: targets, padded with local wires (highest LDS bits first)
       std::vector<char> isr(n, 0);
       std::vector<int> regw;   // wires carrying a fused U first (the fast kernel's stage kinds count them)
