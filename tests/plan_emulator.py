@@ -119,7 +119,6 @@ def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None):
     # (the write-back stays in the thread's own group of 16 slots -- the slots differing in the register positions only;
     # the reads may come from anywhere in the tile: nothing has been written in this stage yet)
     own0 = np.stack(wr)
-    assert len(np.unique(own0[0] ^ own0, axis=1)) == 16 or True
     regmask = 0
     for b in range(4):
         regmask |= int(swz_inv(np.array([wb[b] >> 4]))[0])
