@@ -144,6 +144,9 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
     dp->fast_workgroups = circuit_fast_workgroups_per_cu(1 << (dp->plan.k - 4), flds) * h->num_cus;
     std::vector<uint32_t>().swap(dp->fast.words);   // the host copy is no longer needed (pass_off is)
   }
+  // The uploads above go through the NULL stream; the kernels that read them are launched on the caller's stream, which
+  // (torch's streams) does not synchronise with it.  One device-wide wait per NEW plan.
+  HIPCHK(h, hipDeviceSynchronize());
   *out = dp.get();
   h->plans[key] = std::move(dp);
   return BORNVI_OK;
@@ -249,6 +252,7 @@ int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_count, int
     tabs->chunks.push_back(std::move(ch));
     if (codes.empty()) break;
   }
+  HIPCHK(h, hipDeviceSynchronize());      // (NULL-stream uploads, read by kernels on the caller's stream: see get_plan)
   *out = tabs.get();
   dp->share_cache.push_back(std::move(tabs));
   return BORNVI_OK;
@@ -390,6 +394,7 @@ int get_adj_plan(bornvi_handle h, int ansatz, int n, int layers, AdjPlan** out) 
   DEVICE_SCOPE(h);
   HIPCHK(h, hipMalloc((void**)&ap->d_slot_param, slots.size() * sizeof(int)));
   HIPCHK(h, hipMemcpy(ap->d_slot_param, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(h, hipDeviceSynchronize());      // (NULL-stream uploads, read by kernels on the caller's stream: see get_plan)
   *out = ap.get();
   h->adj_plans[key] = std::move(ap);
   return BORNVI_OK;
@@ -465,6 +470,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   else if (!std::strcmp(name, "tile_bits_multi")) o.kmulti = (int)value;
   else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;
   else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
+  else if (!std::strcmp(name, "read_map")) o.read_map = value != 0;
   else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
   if (o.kmax < 4 || o.kmax > 13 || (o.kmulti != 0 && (o.kmulti < 4 || o.kmulti > 13)) || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
       (o.max_threads & (o.max_threads - 1)))
@@ -928,6 +934,8 @@ int bornvi_debug_circuit_stamps(bornvi_handle h, unsigned long long* out16) {
 
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
   PlanOptions opt;
+  opt.read_map = (tile_bits & 0x100) != 0;       // (bit 8 of tile_bits: the planner's read_map option)
+  tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
   Plan p;
   std::string msg;
@@ -954,6 +962,8 @@ int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, i
 long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words,
                                     uint32_t* pass_off_out, int cap_passes) {
   PlanOptions opt;
+  opt.read_map = (tile_bits & 0x100) != 0;
+  tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
   Plan p;
   std::string msg;

@@ -303,7 +303,13 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
       const uint32_t npayn = (((hdrn >> 8) & STAGE_SIGN_PRE) ? SIGNQ_WORDS : 0) + (((hdrn >> 8) & STAGE_SIGN_POST) ? SIGNQ_WORDS : 0);
       if (t < (1u << (k - (int)(hdrn & 0xffu)))) base_word = Sn[STAGE_HDR_WORDS + npayn + t];
     }
-    if (t < (1u << (k - r))) {
+    // (two halves around an optional workgroup barrier: a stage whose read map crosses thread groups -- plan.hpp:
+    // STAGE_CROSS_READ -- must not write before every thread has read)
+    const bool stage_active = t < (1u << (k - r));
+    const int nreg = 1 << r;
+    uint32_t wbase = 0;
+    double ar[16], ai[16];
+    if (stage_active) {
       const uint32_t rho = G[1];
       const uint32_t fi[4] = {G[6] & 0xffffu, G[6] >> 16, G[7] & 0xffffu, G[7] >> 16};
       const double2* __restrict__ Us = mats + s * 16;
@@ -329,9 +335,8 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
         const uint32_t m = G[48 + p2];
         if (m) lflip ^= (__popc(e & m) & 1) ? lds_swizzle(1u << p2) : 0u;
       }
-      const int nreg = 1 << r;
-      const uint32_t rbase = pb ^ lflip, wbase = pb ^ sflip;
-      double ar[16], ai[16];
+      const uint32_t rbase = pb ^ lflip;
+      wbase = pb ^ sflip;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if ((FULL || j < nreg) && !(dbg & 2)) { const double2 x = tile[rbase ^ G[16 + j]]; ar[j] = x.x; ai[j] = x.y; }
@@ -346,6 +351,9 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
         if (fi[3] != 0xffffu) op_u1<3>(ar, ai, Us + 12);
       }
       if ((sflags & STAGE_SIGN_POST) && !(dbg & 128)) apply_sign(Q, e2, n, ar, ai);
+    }
+    if (sflags & STAGE_CROSS_READ) __syncthreads();
+    if (stage_active) {
 #pragma unroll
       for (int j = 0; j < 16; ++j)
         if ((FULL || j < nreg) && !(dbg & 2)) tile[wbase ^ G[32 + j]] = make_double2(ar[j], ai[j]);
@@ -503,6 +511,9 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // a large-tile workgroup reach the end of a stage together; 16 ds_write_b128 per wave issued in one burst by all of
 // them kept the LDS write path (~80 B/clk/CU) busy for ~1600 cycles per stage with the VALU idle.  Same operations on
 // the same values: bit-identical results.
+#ifndef BORNVI_SKIP_ZERO_TILES
+#define BORNVI_SKIP_ZERO_TILES 1   // 0: run the first pass's all-zero tiles through the stages like any other (A/B)
+#endif
 #ifndef BORNVI_GATE_PRIO
 #define BORNVI_GATE_PRIO 0       // experiment: s_setprio level while a wave runs its gates (0 = off)
 #endif
@@ -631,7 +642,8 @@ __device__ __forceinline__ void op_u1_last_and_store(double (&ar)[16], double (&
 template <int NG, bool PRE, bool POST, int IO, bool DEBUG, bool LT>
 __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const double2* __restrict__ Us, uint32_t my_rw,
                                            uint32_t my_sg, const uint32_t (&G)[10], int dbg, d2_t (&v)[16],
-                                           uint32_t hbm_off, const uint32_t (&hbm_basis)[4], void* hbm_base, bool fin) {
+                                           uint32_t hbm_off, const uint32_t (&hbm_basis)[4], void* hbm_base, bool fin,
+                                           bool cross) {
   double ar[16], ai[16];
 #if BORNVI_U_PREFETCH
   // (first: LDS returns in order, so the first gate can start as soon as ITS amplitudes have arrived behind the matrix)
@@ -657,6 +669,12 @@ __device__ __forceinline__ void stage_body(double2* __restrict__ tile, const dou
         ar[j] = x.x; ai[j] = x.y;
       } else { ar[j] = (double)(ra + j); ai[j] = 0.0; }
     }
+  }
+  if (IO != 1 && cross) {
+    // the read map took amplitudes from other threads' groups (plan.hpp: STAGE_CROSS_READ): nobody writes before
+    // everybody has its 16 amplitudes (wave-uniform flag, same for the whole workgroup)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
   }
   if (PRE) apply_sign_bits(my_sg & 0xffffu, ar, ai);
 #if BORNVI_GATE_PRIO
@@ -752,10 +770,10 @@ template <int IO, bool DEBUG, bool LT>
 __device__ __forceinline__ void stage_dispatch(uint32_t kind, double2* __restrict__ tile, const double2* __restrict__ Us,
                                                uint32_t my_rw, uint32_t my_sg, const uint32_t (&G)[10], int dbg,
                                                d2_t (&v)[16], uint32_t hbm_off, const uint32_t (&hbm_basis)[4],
-                                               void* hbm_base, bool fin) {
+                                               void* hbm_base, bool fin, bool cross) {
 #define BORNVI_STAGE(NG, PRE, POST) \
   case (NG) | ((PRE) << 3) | ((POST) << 4): \
-    stage_body<NG, PRE, POST, IO, DEBUG, LT>(tile, Us, my_rw, my_sg, G, dbg, v, hbm_off, hbm_basis, hbm_base, fin); break;
+    stage_body<NG, PRE, POST, IO, DEBUG, LT>(tile, Us, my_rw, my_sg, G, dbg, v, hbm_off, hbm_basis, hbm_base, fin, cross); break;
 #define BORNVI_STAGE_NG(PRE, POST) \
   BORNVI_STAGE(0, PRE, POST) BORNVI_STAGE(1, PRE, POST) BORNVI_STAGE(2, PRE, POST) BORNVI_STAGE(3, PRE, POST) BORNVI_STAGE(4, PRE, POST)
 #if BORNVI_TIMING_NO_GATES   /* experiment (wrong results): the stages' LDS round trips and signs without the gate arithmetic */
@@ -938,21 +956,38 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     const uint32_t rw_ = tab_rw[(uint32_t)(S_) * T + t];                                                        \
     const uint32_t sg_ = (kind_ >> 3) ? tab_sg[(uint32_t)__popc(sign_any & ((1u << (S_)) - 1u)) * T + t] : 0u;  \
     stage_dispatch<IO_, DEBUG, SPLIT>(kind_, tile, mats + (S_) * 16, rw_, sg_, G_, dbg, v, (IO_) == 2 ? tw_out[t] : 0u, \
-                               out_basis, hbm_base, fin);                                                       \
+                               out_basis, hbm_base, fin, FS_[FS_CROSS] != 0u);                                  \
   } while (0)
   // (direct_mask bit 2: this launch walks the tiles from the last to the first -- alternate passes in opposite directions
   // start on the states the previous pass wrote last, i.e. on what the memory-side cache still holds)
   const long long walk_flip = total_tiles - 1;
   const bool walk_rev = (direct_mask & 4) != 0;
+  const bool zskip = BORNVI_SKIP_ZERO_TILES && !DEBUG && init && gbits > 0 && total_tiles < (1ll << 31);
+  const uint32_t zs_nb = (uint32_t)(total_tiles >> gbits), zs_gm1 = (1u << gbits) - 1u;   // circuits; zero tiles per circuit
   for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x, parity ^= 1u) {
     const bool real = Scur >= 0;
     const long long Snext = Scur + gridDim.x;
     const bool has_next = Snext < total_tiles;
-    const long long Tcur = walk_rev ? walk_flip - Scur : Scur;       // (only used where `real`)
-    const long long Tnext = walk_rev ? walk_flip - Snext : Snext;    // (only used where `has_next`)
+    // INIT passes with zero tiles (see zero_tile below): the one non-zero tile of every circuit first, spread over all
+    // workgroups (with the plain order workgroup w only ever sees tile w mod 2^gbits: an eighth of the workgroups
+    // would do all the work), then the zero tiles
+    long long Tcur, Tnext;
+    if (zskip) {
+      const uint32_t sc = (uint32_t)(real ? Scur : 0), sn = (uint32_t)(has_next ? Snext : 0);
+      const uint32_t bc_ = sc < zs_nb ? sc : (sc - zs_nb) / zs_gm1, bn_ = sn < zs_nb ? sn : (sn - zs_nb) / zs_gm1;
+      Tcur = sc < zs_nb ? ((long long)sc << gbits) : (((long long)bc_ << gbits) | (1u + (sc - zs_nb - bc_ * zs_gm1)));
+      Tnext = sn < zs_nb ? ((long long)sn << gbits) : (((long long)bn_ << gbits) | (1u + (sn - zs_nb - bn_ * zs_gm1)));
+    } else {
+      Tcur = walk_rev ? walk_flip - Scur : Scur;       // (only used where `real`)
+      Tnext = walk_rev ? walk_flip - Snext : Snext;    // (only used where `has_next`)
+    }
     if (!real && !has_next) break;
     const uint32_t g = real ? (uint32_t)(Tcur & ((1ll << gbits) - 1)) : 0u;
     const long long b = real ? (Tcur >> gbits) : 0;
+    // |0..0> lies in tile 0 of its circuit, and the gates of the first pass act inside a tile (a CNOT controlled by a
+    // tile-index wire permutes the tile): every other tile of an INIT pass is zero before and after -- no fill, no
+    // stages, 16 stores of zeros (7 of 8 tiles at n = 16, 127 of 128 at n = 20)
+    const bool zero_tile = zskip && real && g != 0u;
     double2* __restrict__ mats = parity ? mats_b : tile + ksize;         // this tile's matrices
     double2* __restrict__ mats_next = parity ? tile + ksize : mats_b;
     double2* dst = out + b * state_stride;
@@ -974,7 +1009,8 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       // ---- registers -> LDS: the tile (head CNOTs of the pass folded into the slot), unless the first stage
       // takes the registers as they are ----
       if (init) {
-        for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
+        if (!zero_tile)
+          for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
       } else if (!direct_in && !(dbg & 4)) {
         const uint32_t slot_t = (tw_slots[t] & 0xffffu) ^ xor_map16(g, gbits, in_gmask);
 #pragma unroll
@@ -1015,7 +1051,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     BORNVI_STAMP(2);                // head of the prefetch (matrix piece)
     {
       const int s0 = (real && direct_in) ? 1 : 0;
-      const int ns = real ? nstages : 0;
+      const int ns = (real && !zero_tile) ? nstages : 0;
       const int niter = (ns - s0 > 0) ? ns - s0 : 1;
 #ifndef BORNVI_SPLIT_STAGGER
 #define BORNVI_SPLIT_STAGGER 1
@@ -1059,7 +1095,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     BORNVI_STAMP(2);                // issuing the prefetch
     if (real) {
       __syncthreads();                          // the tile (or the first stage's result) is in LDS
-      for (int s = direct_in ? 1 : 0; s < nstages; ++s) {
+      for (int s = direct_in ? 1 : 0; s < (zero_tile ? 0 : nstages); ++s) {
         if (s == nstages - 1 && direct_out) {
           BORNVI_RUN_STAGE(s, 2);
         } else {
@@ -1073,7 +1109,17 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       BORNVI_STAMP(3);              // the stages (LDS round trips, gates, barriers)
       // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
       // vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
-      if (!direct_out) {
+      if (zero_tile) {
+        // the same 16 stores per wave as any other tile (the vmcnt waits count them), of zeros, at the tile drain's addresses
+        const uint32_t gout0 = xor_cols(g, gbits, P + PW_OUT_GCOL) << out_shift;
+        const uint32_t thr0 = xor_cols(t, kt, P + PW_OUT_COL) << out_shift;     // (tw_out may hold a direct stage's row)
+#pragma unroll
+        for (int i = 0; i < MAX_TILE_ITERS; ++i) {
+          const uint32_t off = thr0 ^ gout0 ^ ((i & 1) ? pcol[0] : 0u) ^ ((i & 2) ? pcol[1] : 0u) ^ ((i & 4) ? pcol[2] : 0u) ^ ((i & 8) ? pcol[3] : 0u);
+          if (fin) async_store8(off, 0.0, pdst);
+          else async_store16(off, (d2_t){0.0, 0.0}, dst);
+        }
+      } else if (!direct_out) {
         const uint32_t gout = xor_cols(g, gbits, P + PW_OUT_GCOL) << out_shift;
         const uint32_t thr_l = (tw_slots[t] >> 16) ^ xor_map16(g, gbits, out_gmask);   // tail CNOTs folded in
         const uint32_t thr_out = tw_out[t];
@@ -1095,7 +1141,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     // (these are compiler-tracked loads: they drain vmcnt).  All stages of the current tile are done here. ----
     {
       const uint32_t gnx = (uint32_t)(Tnext & ((1ll << gbits) - 1));
-      if (gnx != g_tab) {
+      if (gnx != g_tab && !(zskip && gnx != 0u)) {     // (a zero tile needs no tables)
         g_tab = gnx;
         uint32_t tt = t;
         asm volatile("" : "+v"(tt));

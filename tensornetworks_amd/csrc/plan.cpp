@@ -184,7 +184,7 @@ struct StageSel {
 // defer_cx3: a CNOT that could only run in phase 3 AND would claim a new register wire is left for the next stage,
 // where it is a phase-0 CNOT (folded into the read map: free) -- the register wires then go to fused U's.
 void stage_select(const std::vector<Op>& ops, const std::vector<int>& pool, int n, int cap, StageSel& S,
-                  std::vector<int>& rest, bool defer_cx3 = false) {
+                  std::vector<int>& rest, bool defer_cx3 = false, bool read_map = false) {
   std::vector<char> blocked(n, 0), in_t(n, 0), has_u(n, 0);
   std::vector<int> wphase(n, 0);
   rest.clear();
@@ -203,7 +203,7 @@ void stage_select(const std::vector<Op>& ops, const std::vector<int>& pool, int 
     // (a phase-0 CNOT is folded into the stage's READ map, which may move any local bit: its target need not be one of
     // the `cap` register wires -- only a fused U and a phase-3 CNOT, whose write-back must stay inside the thread's own
     // group, claim one)
-    if (!blk && t >= 0 && !in_t[t] && !(o.kind == K_CX && ph == 0)) {
+    if (!blk && t >= 0 && !in_t[t] && !(read_map && o.kind == K_CX && ph == 0)) {
       if (defer_cx3 && o.kind == K_CX) blk = true;
       else if ((int)S.targets.size() < cap) { in_t[t] = 1; S.targets.push_back(t); }
       else blk = true;
@@ -281,12 +281,12 @@ void split_pass_ops(const std::vector<Op>& ops, const std::vector<int>& pass_ops
 
 // target wires of the first and of the last stage of a pass (they depend on the ops only, not on the layout)
 // number of stages the core ops of a pass need under a stage-selection policy
-int count_stages(const std::vector<Op>& ops, const std::vector<int>& core, int n, int r, bool defer_cx3) {
+int count_stages(const std::vector<Op>& ops, const std::vector<int>& core, int n, int r, bool defer_cx3, bool read_map) {
   std::vector<int> pool = core, rest;
   int cnt = 0;
   while (!pool.empty()) {
     StageSel sel;
-    stage_select(ops, pool, n, r, sel, rest, defer_cx3);
+    stage_select(ops, pool, n, r, sel, rest, defer_cx3, read_map);
     if (sel.count() == 0) return 1 << 20;
     ++cnt;
     pool = rest;
@@ -294,21 +294,21 @@ int count_stages(const std::vector<Op>& ops, const std::vector<int>& core, int n
   return cnt;
 }
 // the policy with fewer stages (ties: the program-order greedy one)
-bool pick_defer_policy(const std::vector<Op>& ops, const std::vector<int>& core, int n, int r) {
-  return count_stages(ops, core, n, r, true) < count_stages(ops, core, n, r, false);
+bool pick_defer_policy(const std::vector<Op>& ops, const std::vector<int>& core, int n, int r, bool read_map) {
+  return read_map && count_stages(ops, core, n, r, true, true) < count_stages(ops, core, n, r, false, true);
 }
 
 void first_last_stage_targets(const std::vector<Op>& ops, const std::vector<int>& pass_ops, int n, int r, bool is_init,
-                              std::vector<int>& first_t, std::vector<int>& last_t) {
+                              std::vector<int>& first_t, std::vector<int>& last_t, bool read_map) {
   std::vector<int> lead, core, trail, rest;
   split_pass_ops(ops, pass_ops, n, is_init, lead, core, trail);
   first_t.clear(); last_t.clear();
   std::vector<int> pool = core;
   bool first = true;
-  const bool defer = pick_defer_policy(ops, core, n, r);
+  const bool defer = pick_defer_policy(ops, core, n, r, read_map);
   while (!pool.empty()) {
     StageSel sel;
-    stage_select(ops, pool, n, r, sel, rest, defer);
+    stage_select(ops, pool, n, r, sel, rest, defer, read_map);
     if (sel.count() == 0) break;
     if (first) { first_t = sel.targets; first = false; }
     last_t = sel.targets;
@@ -497,8 +497,8 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     // thread index, not from the register wires).  At least 2^4 contiguous elements are kept (256-byte runs).
     {
       std::vector<int> f_cur, l_cur, f_nxt, l_nxt;
-      first_last_stage_targets(ops, P.ops, n, r, i == 0 && !spec.in_state, f_cur, l_cur);
-      first_last_stage_targets(ops, passes[i + 1].ops, n, r, false, f_nxt, l_nxt);
+      first_last_stage_targets(ops, P.ops, n, r, i == 0 && !spec.in_state, f_cur, l_cur, opt.read_map);
+      first_last_stage_targets(ops, passes[i + 1].ops, n, r, false, f_nxt, l_nxt, opt.read_map);
       std::vector<char> busy(n, 0);
       for (int w : l_cur) busy[w] = 1;
       for (int w : f_nxt) busy[w] = 1;
@@ -642,10 +642,10 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     //      the 2^r-element group a thread owns, so the in-place write-back needs no extra barrier.
     std::vector<int> pool = core, rest;
     uint32_t nstages = 0;
-    const bool defer_cx3 = pick_defer_policy(ops, core, n, r);
+    const bool defer_cx3 = pick_defer_policy(ops, core, n, r, opt.read_map);
     while (!pool.empty()) {
       StageSel sel;
-      stage_select(ops, pool, n, r, sel, rest, defer_cx3);
+      stage_select(ops, pool, n, r, sel, rest, defer_cx3, opt.read_map);
       if (sel.count() == 0) { msg = "stage planner made no progress"; return false; }
       if (getenv("BORNVI_PLAN_DEBUG")) {
         auto show = [&](const char* nm, const std::vector<int>& v) {
@@ -791,9 +791,13 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
         W[sbase + 16 + j] = (j < (1 << r)) ? lds_swizzle(read_slot_offset(j)) : 0u;
         W[sbase + 32 + j] = (j < (1 << r)) ? lds_swizzle(slot_offset(post, j)) : 0u;
       }
+      bool cross_read = false;
       for (int p2 = 0; p2 < k; ++p2)          // thread-held positions moved by the read map
-        if (!isr[P.lds_wire[p2]]) W[sbase + 48 + p2] = pre_pos[(size_t)p2].bext ^ (1u << p2);
-      uint32_t flags = io_flags;
+        if (!isr[P.lds_wire[p2]]) {
+          W[sbase + 48 + p2] = pre_pos[(size_t)p2].bext ^ (1u << p2);
+          if (W[sbase + 48 + p2] || pre_pos[(size_t)p2].areg) cross_read = true;
+        }
+      uint32_t flags = io_flags | (cross_read ? STAGE_CROSS_READ : 0u);
       Expr ident[4];
       for (int t = 0; t < 4; ++t) ident[t] = Expr{1u << t, 0u};
       if (!sel.pre_cz.empty()) { flags |= STAGE_SIGN_PRE; emit_signq(sel.pre_cz, ident); }
@@ -898,6 +902,7 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
         for (uint32_t b = ng; b < 4; ++b)
           if (fi[b] != 0xffffu) { out.words.clear(); out.pass_off.clear(); return false; }
         FS[FS_KIND] = ng | ((sflags & STAGE_SIGN_PRE) ? 8u : 0u) | ((sflags & STAGE_SIGN_POST) ? 16u : 0u);
+        FS[FS_CROSS] = (sflags & STAGE_CROSS_READ) ? 1u : 0u;
         if (!fast_stage_kind_supported(FS[FS_KIND])) { out.words.clear(); out.pass_off.clear(); return false; }
       }
       for (int b = 0; b < 4; ++b) { FS[FS_RB + b] = S[16 + (1 << b)] << 4; FS[FS_WB + b] = S[32 + (1 << b)] << 4; }

@@ -107,6 +107,10 @@ constexpr uint32_t STAGE_SIGN_POST = 2u;
 // ignores these flags
 constexpr uint32_t STAGE_FROM_HBM = 4u;
 constexpr uint32_t STAGE_TO_HBM = 8u;
+// the stage's READ map takes amplitudes from other threads' groups (BpreF / slot offsets outside the register positions):
+// every thread must have finished reading before any thread writes -- the kernels put a workgroup barrier between the
+// stage's reads and its write-back
+constexpr uint32_t STAGE_CROSS_READ = 16u;
 // sign payload (product of CZ gates = (-1)^{q(x)}, q a quadratic form over the extended index bits):
 //   [0..31] U rows (upper-triangular adjacency), [32..47] m_j (bilinear masks of the 16 slot
 //   offsets), [48] q bits of the slot offsets
@@ -132,6 +136,9 @@ struct PlanOptions {
   int r = 4;         // register wires per stage (2^4 amplitudes per thread)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 512;
+  bool read_map = false;   // phase-0 CNOTs may target thread-held wires (general GF(2) read map, STAGE_CROSS_READ): fewer
+                           // stages, but such a stage needs a barrier between its reads and its write-back, which costs more than
+                           // the stages saved (MI355X, n = 16 / 20: +3.7 % / +2.8 %): off; kept for A/B (option "read_map")
 };
 
 struct Plan {
@@ -175,7 +182,7 @@ struct Plan {
 //       FH_OUT_BASIS words of the bits of j  (both address maps are GF(2)-linear)
 enum FastHeader : int { FH_NSTAGES = 0, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_IN_TAB, FH_OUT_TAB,
                         FH_IN_BASIS = 8, FH_OUT_BASIS = 12, FH_WORDS = 16 };
-enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10, FS_WORDS = 16 };
+enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10, FS_CROSS = 11 /* STAGE_CROSS_READ */, FS_WORDS = 16 };
 
 // The stage kinds circuit_pass_fast_kernel has a specialised body for (stage_dispatch's switch): 0..4 fused gates on
 // register bits 0..ng-1, with or without either CZ sign product.  A stage of any other kind would issue NO tile stores

@@ -17,6 +17,7 @@ PW_IN_PHYS, PW_IN_GPHYS, PW_OUT_PHYS, PW_OUT_GPHYS, PW_IN_MASK, PW_IN_GMASK, PW_
 PW_WIRE_OF_LDS, PW_WIRE_OF_G, PW_MATS, PW_OUT_COL, PW_OUT_GCOL, PW_STAGES = 64, 96, 128, 192, 208, 224
 PASS_INIT, PASS_FINAL, PASS_FINAL_STATE = 1, 2, 4
 STAGE_HDR_WORDS = 64
+STAGE_CROSS_READ = 16
 STAGE_SIGN_PRE, STAGE_SIGN_POST = 1, 2
 SIGNQ_WORDS = 49
 KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
@@ -274,9 +275,11 @@ def run_plan(W, mats, state_in=None, fast=None):
                 # a thread reads and writes exactly its own 2^r-element group (no cross-thread hazard),
                 # and the groups partition the tile
                 own = np.sort(np.stack([base ^ sum(((j >> i) & 1) << rpos[i] for i in range(r)) for j in range(nreg)]), axis=0)
-                # (reads may come from other threads' groups -- nothing has been written in this stage yet; the write-back
-                # stays inside the thread's own group, so one barrier per stage is enough)
+                # (reads may come from other threads' groups: the stage then carries STAGE_CROSS_READ, and the kernels put a
+                # barrier between its reads and its write-back, which stays inside the thread's own group)
                 assert np.array_equal(np.sort(np.stack(wr), axis=0), own)
+                crosses = not np.array_equal(np.sort(np.stack(rd), axis=0), own)
+                assert bool(sflags & STAGE_CROSS_READ) or not crosses
                 assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(ksize))
                 amp = [tile[rd[j]].copy() for j in range(nreg)] + [np.zeros(nthr, np.complex128)] * (16 - nreg)
                 q_off = STAGE_HDR_WORDS

@@ -310,6 +310,28 @@ def test_alternate_walk_is_bit_identical(be, dev, ansatz, n, L, kb, share):
     np.testing.assert_allclose(alt[2 * P], oc.probs(ansatz, n, L, t2), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb", [(14, 3, 11), (15, 3, 13), (16, 2, 12)])
+def test_read_map_planner_option(be, dev, ansatz, n, L, kb):
+    """Planner option read_map (off by default): phase-0 CNOTs may target thread-held wires; such a stage reads across
+    thread groups and carries a barrier between its reads and its write-back (STAGE_CROSS_READ -- without it the rows
+    were wrong on a cold GPU, where the waves of a workgroup drift apart).  Fewer stages, same circuit: a batch large
+    enough for several tiles per workgroup against the oracle, and against the default plan to rounding."""
+    be.set_option(dev, "tile_bits", kb)
+    P = oc.num_params(ansatz, n, L)
+    th = np.random.default_rng(3 * n + L).uniform(-np.pi, np.pi, P)
+    tht = torch.as_tensor(th, device=dev)
+    try:
+        ref = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+        be.set_option(dev, "read_map", 1)
+        got = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+    finally:
+        be.set_option(dev, "read_map", 0)
+    assert float((got.sum(dim=1) - 1).abs().max()) < 1e-12
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(got[0].cpu().numpy(), oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("n,L,kb", [(8, 2, 13), (14, 2, 11)])
 def test_strided_parameter_set(be, dev, n, L, kb):
     """bornvi_paramshift_probs_strided (the interleaved deal of a multi-GPU step): rows of rank r of W are the rows

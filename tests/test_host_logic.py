@@ -214,10 +214,13 @@ def test_planner_property_random_configurations():
     from hypothesis import given, settings, strategies as st
     from tensornetworks_amd import _ext
 
-    @settings(max_examples=25, deadline=None, derandomize=True)
-    @given(st.sampled_from(oc.ANSATZ_TYPES), st.integers(1, 9), st.integers(0, 3), st.integers(4, 13), st.integers(0, 10 ** 6))
-    def check(ansatz, n, L, kb, seed):
-        W = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, L, kb)
+    @settings(max_examples=30, deadline=None, derandomize=True)
+    @given(st.sampled_from(oc.ANSATZ_TYPES), st.integers(1, 9), st.integers(0, 3), st.integers(4, 13), st.integers(0, 10 ** 6),
+           st.booleans())
+    def check(ansatz, n, L, kb, seed, read_map):
+        # (bit 8 of the tile-size argument: the planner's `read_map` option -- phase-0 CNOTs on thread-held wires, stages
+        # flagged STAGE_CROSS_READ; off in the product, kept correct)
+        W = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, L, kb | (0x100 if read_map else 0))
         th = np.random.default_rng(seed).uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
         q = pe.run_plan(W, pe.fused_matrices(W, th))
         np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
