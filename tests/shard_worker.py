@@ -116,3 +116,24 @@ def rccl_single_rank(rank, world_size, port, out_dir):
         with open(os.path.join(out_dir, f"rank{rank}.err"), "w") as f:
             traceback.print_exc(file=f)
         raise
+
+
+def cold_batch(rank, world_size, port, n, L, read_map, out_dir):
+    """A FRESH process runs one full parameter-shift batch and checks every row's sum: the first launches of a process
+    find cold instruction caches and TLBs, the waves of a workgroup drift apart, and a missing barrier shows (the
+    cross-group read map of round 2 produced wrong rows only here)."""
+    try:
+        import torch
+        from tensornetworks_amd import backend as be
+        dev = torch.device("cuda", 0)
+        be.set_option(dev, "read_map", int(read_map))
+        P = be.num_params("hardware_efficient", n, L)
+        g = torch.Generator().manual_seed(0)
+        th = (0.1 * torch.randn(P, generator=g, dtype=torch.float32)).double().to(dev)
+        full = be.paramshift_probs("hardware_efficient", n, L, th, 0, P, include_base=True)
+        worst = float((full.sum(dim=1) - 1.0).abs().max())
+        np.savez(os.path.join(out_dir, f"cold{rank}.npz"), worst=np.float64(worst))
+    except BaseException:
+        with open(os.path.join(out_dir, f"rank{rank}.err"), "w") as f:
+            traceback.print_exc(file=f)
+        raise

@@ -116,3 +116,14 @@ def test_rccl_group_of_one_runs_the_collective_wrappers(dev, tmp_path):
     codes = run_ranks(shard_worker.rccl_single_rank, 1, (str(tmp_path),), timeout=300)
     assert codes == [0], (codes, _errors(tmp_path))
     assert bool(np.load(tmp_path / "rccl.npz")["ok"])
+
+
+@pytest.mark.parametrize("read_map", [0, 1])
+def test_cold_process_runs_the_full_n20_batch_correctly(dev, tmp_path, read_map):
+    """Two fresh processes each run BASELINE config 4's batch (n = 20, L = 8, 961 circuits) as their FIRST GPU work:
+    every row must sum to 1.  (A stage that read across thread groups without a barrier was right in every warm run
+    and wrong in five of eight cold ones.)"""
+    for trial in range(2):
+        codes = run_ranks(shard_worker.cold_batch, 1, (20, 8, read_map, str(tmp_path)), timeout=300)
+        assert codes == [0], (codes, _errors(tmp_path))
+        assert float(np.load(tmp_path / "cold0.npz")["worst"]) < 1e-12
