@@ -77,6 +77,7 @@ struct bornvi_ctx {
   int grad_engine = 0;      // OPT-IN: 1 = bornvi_paramshift_grad answers with adjoint differentiation (one
                             // forward + one backward walk) instead of 2P shifted circuits; same gradient to rounding
   int batched_quadform = 1; // bornvi_stein_quadform with B > 1: 1 = one MFMA pass over K, 0 = B GEMV passes (A/B switch)
+  int zero_support = 1;     // fast kernel: pass 0 / pass 1 leave out what the support of |0..0> makes known zeros (A/B)
   int alternate_walk = 1;   // fast kernel: odd passes walk the tiles from the last to the first: a pass starts on the states the previous
                             // one wrote last, which the 256 MiB memory-side cache still holds (n = 16: -4.4 %; n = 20: neutral)
   int direct_stages = 3;    // fast kernel: bit 0 / 1 = first / last stage of a pass straight from / to HBM where the plan allows
@@ -196,7 +197,10 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
                                          p.fast_lds_bytes(dp->fast.max_tab_rows), nb, in, out, final_probs, gates, gate_stride, wgs,
                                          p.fast_lds_tab_off(), p.fast_lds_mats2_off(dp->fast.max_tab_rows),
                                          (((h->direct_stages >> 2) && (h->direct_stages >> 2) - 1 != i) ? 0 : (h->direct_stages & 3)) |
-                                             ((h->alternate_walk && (i & 1)) ? 4 : 0),
+                                             ((h->alternate_walk && (i & 1)) ? 4 : 0) |
+                                             // (the zero-support masks of passes 0 and 1 assume both run with their direct
+                                             // first stage on and without debug ablations: plan.cpp FH_ZINFO)
+                                             ((in0 == nullptr && h->direct_stages == 3 && h->debug_flags == 0 && h->zero_support) ? 8 : 0),
                                          h->debug_flags, ps, st));
     } else {
       if (share) return fail(h, BORNVI_ERR_INVALID, "prefix sharing needs the fast circuit kernel");
@@ -458,6 +462,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
     h->grad_engine = (int)value;
     return BORNVI_OK;
   }
+  if (!std::strcmp(name, "zero_support")) { h->zero_support = value != 0; return BORNVI_OK; }
   if (!std::strcmp(name, "alternate_walk")) { h->alternate_walk = value != 0; return BORNVI_OK; }
   if (!std::strcmp(name, "direct_stages")) { h->direct_stages = (int)value; return BORNVI_OK; }   // bits 2..: 1 + the only pass allowed (debug)
   if (!std::strcmp(name, "fast_workgroups_per_cu")) {

@@ -921,7 +921,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       g_pref = gn_;                                                                                  \
       tw_in[tt_] = fast[in_tab + (gn_ << kt) + tt_];                                                 \
     }                                                                                                \
-    if (tt_ < npieces) async_load16(mp, tw_mat[tt_], gsrc_);                                         \
+    if (tt_ < npieces && !next_zero) async_load16(mp, tw_mat[tt_], gsrc_);                           \
     if (!init && !(dbg & 4)) {                                                                       \
       /* one per-thread base offset, 16 wave-uniform offsets xor-ed in (both maps are bitwise disjoint or   \
          GF(2)-linear); the empty asm keeps the 16 sums from being hoisted out of the tile loop and spilled */ \
@@ -930,8 +930,9 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       const double2* src_ = in + (bn_ >= share.fresh_begin ? 0ll : bn_) * state_stride +             \
                             (direct_in ? 0u : deposit16(gn_, 0, gbits, in_gphys));                  \
       _Pragma("unroll") for (int i = 0; i < MAX_TILE_ITERS; ++i)                                     \
-        async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^      \
-                                    ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
+        if (!((zslots >> i) & 1u))                                                                   \
+          async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^    \
+                                      ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
     }                                                                                                \
   } while (0)
 
@@ -963,6 +964,13 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
   const long long walk_flip = total_tiles - 1;
   const bool walk_rev = (direct_mask & 4) != 0;
   const bool zskip = BORNVI_SKIP_ZERO_TILES && !DEBUG && init && gbits > 0 && total_tiles < (1ll << 31);
+  // direct_mask bit 3: the launcher vouches that pass 0 and pass 1 of this batch both run with the direct first stage
+  // on, so the masks of FH_ZINFO (plan.cpp: support of |0..0>) hold: an INIT pass leaves out the tiles nobody will
+  // read (zgmask), the pass behind it does not load the slots known to be zero (zslots; v[] is zero from the start of
+  // the kernel and those registers are never loaded, so the first stage finds zeros there)
+  const uint32_t zinfo = (BORNVI_SKIP_ZERO_TILES && !DEBUG && (direct_mask & 8)) ? F[FH_ZINFO] : 0u;
+  const uint32_t zgmask = zskip ? zinfo : 0u;
+  const uint32_t zslots = (!init && direct_in) ? (zinfo & 0xffffu) : 0u;
   const uint32_t zs_nb = (uint32_t)(total_tiles >> gbits), zs_gm1 = (1u << gbits) - 1u;   // circuits; zero tiles per circuit
   for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x, parity ^= 1u) {
     const bool real = Scur >= 0;
@@ -988,6 +996,8 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     // tile-index wire permutes the tile): every other tile of an INIT pass is zero before and after -- no fill, no
     // stages, 16 stores of zeros (7 of 8 tiles at n = 16, 127 of 128 at n = 20)
     const bool zero_tile = zskip && real && g != 0u;
+    const bool noop_tile = zero_tile && (g & zgmask) != 0u;          // nobody reads this tile: not even the zeros are written
+    const bool next_zero = zskip && has_next && (Tnext & ((1ll << gbits) - 1)) != 0;   // (needs no matrices)
     double2* __restrict__ mats = parity ? mats_b : tile + ksize;         // this tile's matrices
     double2* __restrict__ mats_next = parity ? tile + ksize : mats_b;
     double2* dst = out + b * state_stride;
@@ -1045,7 +1055,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
         g_pref = gn_h;
         tw_in[tt_] = fast[in_tab + (gn_h << kt) + tt_];
       }
-      if (tt_ < npieces) async_load16(mp, tw_mat[tt_], gates + bn_h * gate_stride);
+      if (tt_ < npieces && !next_zero) async_load16(mp, tw_mat[tt_], gates + bn_h * gate_stride);
     }
     const bool want_v = has_next && !init && !(dbg & 4);
     BORNVI_STAMP(2);                // head of the prefetch (matrix piece)
@@ -1068,8 +1078,9 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
           const double2* src_ = in + (bn_h >= share.fresh_begin ? 0ll : bn_h) * state_stride +       \
                                 (direct_in ? 0u : deposit16(gn_h, 0, gbits, in_gphys));             \
           _Pragma("unroll") for (int i = 8 * (C_); i < 8 * (C_) + 8; ++i)                            \
-            async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^  \
-                                        ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
+            if (!((zslots >> i) & 1u))   /* (wave-uniform: a slot known to hold zeros is not loaded) */ \
+              async_load16(v[i], base_ ^ (((i & 1) ? in_step[0] : 0u) ^ ((i & 2) ? in_step[1] : 0u) ^  \
+                                          ((i & 4) ? in_step[2] : 0u) ^ ((i & 8) ? in_step[3] : 0u)), src_); \
         }
         BORNVI_PREFETCH_HALF(0)
         BORNVI_PREFETCH_HALF(1)
@@ -1109,7 +1120,8 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
       BORNVI_STAMP(3);              // the stages (LDS round trips, gates, barriers)
       // ---- tile out: LDS -> HBM in the next pass's bit order, or |psi|^2 in canonical order: exactly 16
       // vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
-      if (zero_tile) {
+      if (noop_tile) {
+      } else if (zero_tile) {
         // the same 16 stores per wave as any other tile (the vmcnt waits count them), of zeros, at the tile drain's addresses
         const uint32_t gout0 = xor_cols(g, gbits, P + PW_OUT_GCOL) << out_shift;
         const uint32_t thr0 = xor_cols(t, kt, P + PW_OUT_COL) << out_shift;     // (tw_out may hold a direct stage's row)
@@ -1157,7 +1169,7 @@ __global__ __launch_bounds__(512) void circuit_pass_fast_kernel(
     // ---- the next tile's matrices (the oldest loads in flight: everything but the 16 amplitude loads and the 16
     // stores behind them is done after vmcnt(32); trip -1 and INIT passes have fewer ops in flight) -> the other buffer ----
     if (DEBUG || !real) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (init) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (init || zslots) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // (fewer than 16 loads in flight: all but the stores)
     else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     asm volatile("" : "+v"(mp));
     if (t < npieces) mats_next[t] = make_double2(mp.x, mp.y);

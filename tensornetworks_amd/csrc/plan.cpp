@@ -992,6 +992,36 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
         if (ok) {
           W[hbase + FH_IN_TAB] = tab;
           for (int b = 0; b < 4; ++b) W[hbase + FH_IN_BASIS + b] = basis[b];
+          // Support of |0..0>.  After an INIT pass 0 the state is zero wherever one of pass 0's tile-index wires is 1
+          // (its gates act inside a tile).  If this is pass 1 and those wires' address bits reach the direct first
+          // stage only through the SLOT offsets (never through a thread's base), slot j of every thread is known to be
+          // zero whenever its offset carries one of them: the kernel does not load it (FH_ZINFO of this pass = mask of
+          // such slots), and pass 0 need not write the tiles that only such slots would read (FH_ZINFO of pass 0 = mask
+          // over its tile-index bits: tile g is skipped when g & mask != 0).  Zero-wire bits that sit in thread bases
+          // stay out of both masks (those loads happen and read the zeros pass 0 writes).
+          if (i == 1 && (plan.words[plan.pass_off[0] + PW_FLAGS] & PASS_INIT) && plan.n_passes > 2) {
+            const uint32_t* P0 = plan.words.data() + plan.pass_off[0];
+            uint32_t zbits = 0;                                   // byte-offset bits of pass 0's tile-index wires
+            for (int m = 0; m < n - k; ++m) zbits |= 16u << ((P0[PW_OUT_GPHYS + (m >> 2)] >> (8 * (m & 3))) & 0xffu);
+            uint32_t in_base = 0, in_slot = 0;
+            for (uint32_t g = 0; g < ngl; ++g)
+              for (uint32_t t = 0; t < (1u << kt2); ++t) in_base |= W[tab + ((size_t)g << kt2) + t] & zbits;
+            for (int b = 0; b < 4; ++b) in_slot |= basis[b] & zbits;
+            const uint32_t zs = in_slot & ~in_base;               // zero-wire bits that only slots carry
+            if (zs) {
+              uint32_t zslots = 0;
+              for (int j = 0; j < 16; ++j) {
+                uint32_t off = 0;
+                for (int b = 0; b < 4; ++b) if (j >> b & 1) off ^= basis[b];
+                if (off & zs) zslots |= 1u << j;
+              }
+              uint32_t gmask0 = 0;
+              for (int m = 0; m < n - k; ++m)
+                if (zs & (16u << ((P0[PW_OUT_GPHYS + (m >> 2)] >> (8 * (m & 3))) & 0xffu))) gmask0 |= 1u << m;
+              W[hbase + FH_ZINFO] = zslots;
+              W[out.pass_off[0] + FH_ZINFO] = gmask0;
+            }
+          }
         } else {
           W.resize(tab);
         }

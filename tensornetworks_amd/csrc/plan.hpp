@@ -181,6 +181,7 @@ struct Plan {
 //       pass reads (first stage) resp. writes (last stage); slot j is at  offset ^ xor of the FH_IN_BASIS /
 //       FH_OUT_BASIS words of the bits of j  (both address maps are GF(2)-linear)
 enum FastHeader : int { FH_NSTAGES = 0, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_IN_TAB, FH_OUT_TAB,
+                        FH_ZINFO = 7,   // support of |0..0>: see build_fast_tables (INIT pass: tiles nobody reads; next pass: zero slots)
                         FH_IN_BASIS = 8, FH_OUT_BASIS = 12, FH_WORDS = 16 };
 enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10, FS_CROSS = 11 /* STAGE_CROSS_READ */, FS_WORDS = 16 };
 

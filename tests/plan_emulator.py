@@ -24,6 +24,7 @@ KIND_NAMES = {0: "H", 1: "RX", 2: "RY", 3: "RZ"}
 # fast-path tables (plan.hpp: FastHeader / FastStage)
 FH_NSTAGES, FH_RW_BASE, FH_SG_BASE, FH_SIGN_PRE, FH_SIGN_POST, FH_IN_TAB, FH_OUT_TAB = 0, 1, 2, 3, 4, 5, 6
 FH_IN_BASIS, FH_OUT_BASIS, FH_WORDS = 8, 12, 16
+FH_ZINFO = 7      # support of |0..0>: INIT pass = mask over tile-index bits of the tiles nobody reads; next pass = zero slots
 STAGE_FROM_HBM, STAGE_TO_HBM = 4, 8
 FS_FI01, FS_FI23, FS_RB, FS_WB, FS_KIND, FS_WORDS = 0, 1, 2, 6, 10, 16
 
@@ -85,7 +86,7 @@ def popc(x):
     return c
 
 
-def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None):
+def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None, zslots=0):
     """One stage exactly as circuit_pass_fast_kernel runs it: slots and signs from the planner tables.
     direct_in = (buf, lo_in): the first stage takes its amplitudes straight from the pass's input buffer at the byte
     offsets of the FH_IN_TAB table (the tile, filled the ordinary way, must hold the same values);
@@ -136,6 +137,12 @@ def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None):
                 if (j >> b) & 1:
                     off ^= basis[b]
             assert np.all(off % 16 == 0)
+            if (zslots >> j) & 1:
+                # known zero (support of |0..0>): the kernel does not load this slot -- what lies there is either the
+                # zeros pass 0 wrote or the poison of a tile it left out; the stage computes with 0
+                assert np.all((buf[off >> 4] == 0) | np.isnan(buf[off >> 4]))
+                amp[j] = np.zeros_like(amp[j])
+                continue
             np.testing.assert_array_equal(buf[off >> 4], amp[j])      # same amplitudes as through the tile
             lanes = 1 << min(lo_in, 6)
             for w0 in range(0, nthr, lanes):                          # each group of 2^lo_in lanes loads one aligned run
@@ -232,8 +239,9 @@ def run_plan(W, mats, state_in=None, fast=None):
                 phys_of_slot[lds_v] = phys_v
                 use_in = int(Fw[FH + FH_IN_TAB]) != 0 and not (flags & PASS_INIT) and nst > 0
                 use_out = int(Fw[FH + FH_OUT_TAB]) != 0 and nst > 1
+                zslots = int(Fw[FH + FH_ZINFO]) & 0xFFFF if (use_in and not (flags & PASS_INIT)) else 0
                 for si in range(nst):
-                    fast_stage(Fw, FH, si, g, k, n, tile, mats,
+                    fast_stage(Fw, FH, si, g, k, n, tile, mats, zslots=zslots if si == 0 else 0,
                                direct_in=(buf, lo_in) if (si == 0 and use_in) else None,
                                direct_out=(phys_of_slot, 3 if (flags & PASS_FINAL) else 4) if (si == nst - 1 and use_out) else None)
             for si in range(nst if fast is None else 0):
@@ -335,6 +343,9 @@ def run_plan(W, mats, state_in=None, fast=None):
             assert np.array_equal(np.sort(lds), np.arange(ksize))
             if flags & PASS_FINAL:
                 probs[phys] = np.abs(tile[lds]) ** 2
+            elif fast is not None and (flags & PASS_INIT) and (g & int(fast[0][int(fast[1][pi]) + FH_ZINFO])):
+                assert not np.any(tile)                    # a tile the INIT pass leaves out is all zero ...
+                out[phys] = np.nan                         # ... and nobody may read what lies there instead
             else:
                 out[phys] = tile[lds]
         assert np.all(written == 1)      # the phys-out map is a bijection

@@ -74,6 +74,33 @@ def test_fast_tables_against_oracle(ansatz, n, L, kb):
     np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
 
 
+def test_zero_support_masks_leave_out_only_zeros():
+    """Support of |0..0> (fast tables, FH_ZINFO): the INIT pass leaves out tiles nobody reads, the pass behind it does
+    not load slots known to be zero.  The emulator writes NaN where a left-out tile would have gone and computes with 0
+    where a slot is not loaded (asserting that only zeros or that poison lie there): the plan still reproduces the
+    oracle -- and the masks are really in use at the sizes that matter."""
+    from tensornetworks_amd import _ext
+    used = 0
+    for ansatz, n, L, kb in [("all_to_all", 13, 2, 10), ("hardware_efficient", 14, 3, 10), ("basic", 14, 3, 11),
+                             ("hardware_efficient", 13, 3, 10), ("all_to_all", 14, 2, 11)]:
+        aid = _ext.ANSATZ_IDS[ansatz]
+        W = _ext.plan_words(aid, n, L, kb)
+        F, offs = _ext.plan_fast_words(aid, n, L, kb)
+        if F is None:                                     # (not eligible for the persistent kernel at this tile size)
+            continue
+        gmask, zslots = int(F[offs[0] + pe.FH_ZINFO]), int(F[offs[1] + pe.FH_ZINFO])
+        assert (gmask == 0) == (zslots == 0)
+        used += gmask != 0
+        th = np.random.default_rng(n + L).uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
+        q = pe.run_plan(W, pe.fused_matrices(W, th), fast=(F, offs))
+        np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
+    assert used >= 2
+    for n, L in ((16, 6), (20, 8)):                      # the benchmark sizes: one resp. 8 of 2^(n-13) tiles written, 2 resp. 1 of 16 slots loaded
+        F, offs = _ext.plan_fast_words(0, n, L, 0)
+        gmask, zslots = int(F[offs[0] + pe.FH_ZINFO]), int(F[offs[1] + pe.FH_ZINFO])
+        assert bin(gmask).count("1") == min(n - 13, 4) and bin(zslots).count("1") == 16 - (16 >> min(n - 13, 4))
+
+
 def test_fast_tables_eligibility_and_kron():
     from tensornetworks_amd import _ext
     # the first / last stages of multi-pass plans go straight between HBM and registers (coalescing checked by
