@@ -420,7 +420,20 @@ def kernel_table(m, D, args):
     first_pass = _ext.plan_param_first_pass(plan)[list(range(0, P, world))] if n_passes > 1 else None
     share_on = n_passes > 1 and bool(args.prefix_share)
     active = [1 + 2 * int((first_pass <= i).sum()) if share_on else circuits_rank for i in range(n_passes)] if n_passes > 1 else [circuits_rank]
-    circ_bytes = sum(a * ((16.0 * N if i > 0 else 0.0) + (16.0 * N if i < n_passes - 1 else 8.0 * N)) for i, a in enumerate(active))
+    # support of |0..0> (fast tables, FH_ZINFO = word 7 of a pass header): pass 0 writes only the tiles somebody reads,
+    # pass 1 loads only the slots not known to be zero -- the algorithmic bytes are what is left
+    w0 = r1 = 1.0
+    zero_note = ""
+    if n_passes > 2 and not any(o.startswith(("zero_support=0", "direct_stages=")) for o in args.opt) and not args.debug_flags:
+        fw = _ext.plan_fast_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)
+        if fw[0] is not None:
+            gmask, zslots = int(fw[0][fw[1][0] + 7]), int(fw[0][fw[1][1] + 7]) & 0xFFFF
+            w0, r1 = 0.5 ** bin(gmask).count("1"), (16 - bin(zslots).count("1")) / 16.0
+            if gmask:
+                zero_note = (f"; pass 0 writes {w0:.4g} of a state (tiles outside the support of |0..0> that nobody reads are "
+                             f"left out), pass 1 reads {r1:.4g} of one (slots known to be zero are not loaded)")
+    circ_bytes = sum(a * ((16.0 * N * (r1 if i == 1 else 1.0) if i > 0 else 0.0) +
+                          (16.0 * N * (w0 if i == 0 else 1.0) if i < n_passes - 1 else 8.0 * N)) for i, a in enumerate(active))
     rows_rank = -(-N // world)
     sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
     stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
@@ -461,8 +474,8 @@ def kernel_table(m, D, args):
                                 "traffic_source": pmc_src if t_circ else None,
                                 "circuit_passes_run": sum(active), "circuit_passes_without_prefix_sharing": circuits_rank * n_passes,
                                 "survey_8d_unfused_equivalent_gbs": round(unfused_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
-                                "note": "fused LDS-tiled engine: algorithmic bytes = each state read and written once per pass; "
-                                        "the same work as un-fused gate-apply (SURVEY 8(d): 32 * 2^n bytes per gate per state) "
+                                "note": "fused LDS-tiled engine: algorithmic bytes = each state read and written once per pass" + zero_note +
+                                        "; the same work as un-fused gate-apply (SURVEY 8(d): 32 * 2^n bytes per gate per state) "
                                         "would need the survey_8d_unfused_equivalent_gbs rate"},
         stein_name: {
             "bound": "hbm", "launches_per_step": stein_launches,
