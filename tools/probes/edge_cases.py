@@ -5,7 +5,6 @@ sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from tensornetworks_amd import backend as be
 from tensornetworks_amd.bayesian_network import pack_network, synthetic_network
-from oracle import circuit as oc
 dev = torch.device('cuda', 0)
 def tryit(name, fn):
     try:
@@ -15,9 +14,9 @@ def tryit(name, fn):
         print('err ', name, str(e)[:100], flush=True)
     except Exception as e:
         print('EXC ', name, type(e).__name__, str(e)[:100], flush=True)
-for ansatz in oc.ANSATZ_TYPES:
+for ansatz in ("hardware_efficient", "all_to_all", "basic"):
     for n, L in [(1, 0), (1, 1), (2, 1), (13, 1), (14, 1)]:
-        P = oc.num_params(ansatz, n, L)
+        P = be.num_params(ansatz, n, L)
         th = torch.zeros(P, dtype=torch.float64, device=dev)
         tryit(f'{ansatz} n{n} L{L} batch0', lambda: tuple(be.circuit_probs(ansatz, n, L, torch.zeros((0, P), dtype=torch.float64, device=dev)).shape))
         tryit(f'{ansatz} n{n} L{L} shift empty range', lambda: tuple(be.paramshift_probs(ansatz, n, L, th, P, P, include_base=False).shape))
