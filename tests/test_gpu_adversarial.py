@@ -104,3 +104,27 @@ def test_graphed_epochs_run_the_same_training():
     # the first two epochs are the same eager code with the same random numbers
     np.testing.assert_allclose(runs[True][0]["loss_classifier"][:2], runs[False][0]["loss_classifier"][:2], rtol=1e-6)
     np.testing.assert_allclose(runs[True][0]["loss_born_machine"][:2], runs[False][0]["loss_born_machine"][:2], rtol=1e-5, atol=1e-7)
+
+
+def test_classifier_batch_split_gradient_equals_the_plain_layers():
+    """BinaryClassifierMLP on a large GPU batch routes its Linear layers through a weight gradient reduced over the batch
+    in chunks (one library GEMM with K = 131,072 used one or two workgroups): same logits, same gradients to fp32
+    rounding as the plain nn.Sequential, same parameters / state_dict."""
+    from tensornetworks_amd.classifier_pytorch import BinaryClassifierMLP
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    clf = BinaryClassifierMLP(12).to(dev)
+    x = torch.randn(16384, 12, device=dev)
+    y = (torch.rand(16384, 1, device=dev) > 0.5).float()
+    crit = torch.nn.BCEWithLogitsLoss()
+    out_a = clf(x)                                         # chunked path (batch >= 8192, grad enabled)
+    crit(out_a, y).backward()
+    ga = [p.grad.clone() for p in clf.parameters()]
+    clf.zero_grad()
+    out_b = clf.network(x)                                 # the plain layers
+    crit(out_b, y).backward()
+    gb = [p.grad.clone() for p in clf.parameters()]
+    assert torch.allclose(out_a, out_b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(ga, gb):
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), float((a - b).abs().max())
+    assert list(clf.state_dict().keys()) == [f"network.{i}.{k}" for i in (0, 2, 4) for k in ("weight", "bias")]
