@@ -122,16 +122,21 @@ def clip_cast_grad(grad64, max_norm):
     return g32, norm
 
 
-def clip_cast_grad_guard(grad64, max_norm, loss):
+def clip_cast_grad_guard(grad64, max_norm, loss, out=None, found_out=None):
     """clip_cast_grad plus the NaN/Inf guard of the loss as a device flag: -> (g32, norm [0-dim], found_inf [0-dim]
-    float32, 1.0 when loss [1] float64 is NaN or +-Inf), one launch."""
+    float32, 1.0 when loss [1] float64 is NaN or +-Inf), one launch.  out / found_out: destinations to write into
+    (theta.grad and the optimiser's found_inf tensor in a captured step: two copy nodes fewer per replay)."""
     dev = grad64.device
     h = _ext.handle_for(dev)
     _chk(grad64, torch.float64, dev, "grad64")
     _chk(loss, torch.float64, dev, "loss")
-    g32 = torch.empty(grad64.shape, dtype=torch.float32, device=dev)
+    if out is not None:
+        _chk(out, torch.float32, dev, "out", grad64.numel())
+    if found_out is not None:
+        _chk(found_out, torch.float32, dev, "found_out", 1)
+    g32 = out if out is not None else torch.empty(grad64.shape, dtype=torch.float32, device=dev)
     norm = torch.empty((), dtype=torch.float32, device=dev)
-    found = torch.empty((), dtype=torch.float32, device=dev)
+    found = found_out if found_out is not None else torch.empty((), dtype=torch.float32, device=dev)
     h.call("bornvi_clip_cast_grad_guard", grad64.numel(), _ptr(grad64), float(max_norm), _ptr(loss), _ptr(g32), _ptr(norm),
            _ptr(found), _ext.stream_ptr(dev))
     return g32, norm, found

@@ -547,9 +547,10 @@ class KSDVariationalInference:
 
         def body():
             loss_t, grad64, q = self.ksd_and_grad()
-            g32, grad_norm, found_inf = backend.clip_cast_grad_guard(grad64, gradient_clip_norm, loss_t)
-            theta.grad.copy_(g32)
-            found.copy_(found_inf)
+            # (the clipped gradient and the guard flag are written straight into theta.grad and the flag tensor the fused
+            # Adam kernel reads: no copy nodes in the graph)
+            _, grad_norm, _ = backend.clip_cast_grad_guard(grad64, gradient_clip_norm, loss_t,
+                                                           out=theta.grad.view(grad64.shape), found_out=found)
             optimizer_born.found_inf = found
             try:
                 optimizer_born.step()

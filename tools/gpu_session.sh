@@ -148,6 +148,20 @@ for r in rows[:22]:
     print('%-70s calls %6s avg_us %9.1f  pct %5.1f' % (r['Name'].split('(')[0][-70:], r['Calls'], float(r['AverageNs'])/1e3, 100*float(r['TotalDurationNs'])/tot))
 PY
 }
+prof_small() {
+  cd /tmp; rm -rf /root/repo/gpurun_out/prof_small
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_small -- python3 /root/repo/bench.py --steps 200 --warmup 5 --workload ${SMALL_WL:-n8_L4_dense} --no-cpu-baseline --no-gate-bench --no-extras --series none > /root/repo/gpurun_out/prof_small.log 2>&1
+  rc=$?; echo "rc=$rc"; [ $rc -ge 124 ] && exit 1
+  cd /root/repo
+  f=$(ls -t gpurun_out/prof_small/*/*kernel_stats.csv | head -1)
+  python3 - "$f" <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:16]:
+    print('%-70s calls %6s avg_us %9.1f  pct %5.1f' % (r['Name'].split('(')[0][-70:], r['Calls'], float(r['AverageNs'])/1e3, 100*float(r['TotalDurationNs'])/tot))
+PY
+}
 smoke() { run 300 r2_smoke.log python __graft_entry__.py smoke; tail -n 5 gpurun_out/r2_smoke.log; }
 stream() { run 300 r2_stream_probe_zero.log tools/_variants/stream_probe 3 0 0; cat gpurun_out/r2_stream_probe_zero.log
            run 300 r2_stream_probe_rand.log tools/_variants/stream_probe 3 0 1; cat gpurun_out/r2_stream_probe_rand.log; }
