@@ -581,6 +581,13 @@ __device__ __forceinline__ void op_u1_last_and_write(double (&ar)[16], double (&
 #define BORNVI_POLICY_CAT(X_) BORNVI_POLICY_CAT_(X_)
 #define BORNVI_LOAD_MOD BORNVI_POLICY_CAT(BORNVI_LOAD_POLICY)
 #define BORNVI_STORE_MOD BORNVI_POLICY_CAT(BORNVI_STORE_POLICY)
+// the 8-byte probability stores of the last pass: the circuit-ending CNOT ring puts the lanes' parity into a high address
+// bit, so one store instruction writes every other 8-byte element of two 512-byte runs and a neighbouring instruction
+// of the same wave fills the gaps -- these must meet in the L2 (write-back), not stream past it
+#ifndef BORNVI_STORE8_POLICY
+#define BORNVI_STORE8_POLICY 0
+#endif
+#define BORNVI_STORE8_MOD BORNVI_POLICY_CAT(BORNVI_STORE8_POLICY)
 __device__ __forceinline__ void async_load16(d2_t& dst, uint32_t byte_off, const void* base) {
   asm volatile("global_load_dwordx4 %0, %1, %2" BORNVI_LOAD_MOD : "+v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
@@ -590,7 +597,7 @@ __device__ __forceinline__ void async_store16(uint32_t byte_off, d2_t val, void*
   asm volatile("global_store_dwordx4 %0, %1, %2" BORNVI_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(val), "s"(base) : "memory");
 }
 __device__ __forceinline__ void async_store8(uint32_t byte_off, double val, void* base) {
-  asm volatile("global_store_dwordx2 %0, %1, %2" BORNVI_STORE_MOD : : "v"(byte_off), "v"(val), "s"(base) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, %2" BORNVI_STORE8_MOD : : "v"(byte_off), "v"(val), "s"(base) : "memory");
 }
 
 // The same for a direct last stage (IO == 2): the pair's two results go straight to HBM behind its gate -- the 16
