@@ -301,6 +301,14 @@ int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, i
 long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
                                     size_t cap_words, uint32_t* pass_off_out, int cap_passes);
 
+/* `tile_bits` of the three functions above: bits 0-7 tile size (0 = default), bit 8 the planner's read_map option, bit 9
+ * (0x200) the plan with 3 register wires per stage (8 amplitudes per thread) that the high-occupancy pass kernel runs.
+ *
+ * The COMPACT tables of that plan (every per-(tile row, thread) word of the fast tables is GF(2)-affine in (tile row,
+ * thread): one word per lane plus one per (tile row, wave)); same return convention.  Host only; CPU tests. */
+long long bornvi_plan_compact_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
+                                       size_t cap_words, uint32_t* pass_off_out, int cap_passes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,8 @@ _PROTOS = {
     "bornvi_plan_param_first_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "bornvi_plan_fast_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
                                                  C.POINTER(C.c_uint32), C.c_int]),
+    "bornvi_plan_compact_describe": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
+                                                    C.POINTER(C.c_uint32), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -171,6 +173,26 @@ def plan_fast_words(ansatz_id, n, layers, tile_bits=0):
     buf = (C.c_uint32 * need)()
     offs = (C.c_uint32 * npass)()
     L.bornvi_plan_fast_describe(ansatz_id, n, layers, tile_bits, buf, need, offs, npass)
+    return np.frombuffer(buf, dtype=np.uint32).copy(), np.frombuffer(offs, dtype=np.uint32).copy()
+
+
+R3 = 0x200     # flag in `tile_bits` of the plan_* helpers: the 3-register-wire plan (8 amplitudes per thread)
+
+
+def plan_compact_words(ansatz_id, n, layers, tile_bits=0):
+    """Compact tables of the 3-register-wire plan (plan.hpp: CompactTables): (words, pass offsets) or (None, None) when the
+    plan is not eligible for circuit_pass_r3_kernel.  The library checks every word against its point evaluation."""
+    import numpy as np
+    L = lib()
+    need = L.bornvi_plan_compact_describe(ansatz_id, n, layers, tile_bits, None, 0, None, 0)
+    if need < 0:
+        raise BornviError("bornvi_plan_compact_describe: unsupported configuration")
+    if need == 0:
+        return None, None
+    npass = int(plan_words(ansatz_id, n, layers, tile_bits | R3)[3])
+    buf = (C.c_uint32 * need)()
+    offs = (C.c_uint32 * npass)()
+    L.bornvi_plan_compact_describe(ansatz_id, n, layers, tile_bits, buf, need, offs, npass)
     return np.frombuffer(buf, dtype=np.uint32).copy(), np.frombuffer(offs, dtype=np.uint32).copy()
 
 

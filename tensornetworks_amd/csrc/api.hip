@@ -26,6 +26,11 @@ struct DevPlan {
   FastTables fast;
   uint32_t* d_fast = nullptr;
   int fast_workgroups = 0;   // co-resident workgroups of circuit_pass_fast_kernel on the whole device
+  // plans with 3 register wires (8 amplitudes per thread): compact tables + circuit_pass_r3_kernel
+  CompactTables compact;
+  uint32_t* d_compact = nullptr;
+  size_t r3_lds = 0;
+  int r3_workgroups = 0;
   // prefix sharing of parameter-shift batches (circuit_batch): device tables per (parameter range, chunk capacity)
   struct ShareChunk {
     int bc = 0;                        // circuits in the chunk, slot 0 = the base circuit
@@ -65,6 +70,7 @@ struct bornvi_ctx {
   std::map<std::tuple<int, int, int>, std::unique_ptr<DevPlan>> plans;  // (ansatz | -1 = kron, n, layers)
   std::map<std::tuple<int, int, int>, std::unique_ptr<AdjPlan>> adj_plans;
   size_t max_lds_prepared = 0;
+  size_t max_r3_lds_prepared = 0;
   int debug_flags = 0;  // timing-only ablations of circuit_pass_kernel (results are WRONG when non-zero)
   int num_cus = 256;    // multiProcessorCount
   int circuit_cus = 0;  // > 0: size the persistent circuit grid for this many CUs (the caller launches on a CU-masked stream)
@@ -122,10 +128,42 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
   if (it != h->plans.end()) { *out = it->second.get(); return BORNVI_OK; }
   auto dp = std::make_unique<DevPlan>();
   std::string msg;
-  const bool ok = (ansatz == -1) ? make_kron_plan(n, h->opt, dp->plan, msg)
-                                 : make_plan(ansatz, n, layers, h->opt, dp->plan, msg);
+  bool ok = false, use_r3 = false;
+  if (h->opt.r == 3) {
+    // 8 amplitudes per thread where the plan is eligible for circuit_pass_r3_kernel (compact tables, tile and tables
+    // within the CU's LDS); otherwise the 16-amplitude plan below
+    std::string m3;
+    ok = (ansatz == -1) ? make_kron_plan(n, h->opt, dp->plan, m3) : make_plan(ansatz, n, layers, h->opt, dp->plan, m3);
+    use_r3 = ok && dp->plan.r == 3 && build_compact_tables(dp->plan, dp->compact, m3) &&
+             dp->compact.lds_bytes(dp->plan.k) <= MAX_LDS_BYTES;
+    if (!use_r3) { dp = std::make_unique<DevPlan>(); ok = false; }
+  }
+  if (!ok) {
+    PlanOptions o4 = h->opt;
+    o4.r = 4;
+    if (o4.max_threads > 512) o4.max_threads = 512;
+    ok = (ansatz == -1) ? make_kron_plan(n, o4, dp->plan, msg) : make_plan(ansatz, n, layers, o4, dp->plan, msg);
+  }
   if (!ok) return fail(h, BORNVI_ERR_UNSUPPORTED, msg);
   DEVICE_SCOPE(h);
+  if (use_r3) {
+    HIPCHK(h, hipMalloc((void**)&dp->d_words, dp->plan.words.size() * sizeof(uint32_t)));
+    HIPCHK(h, hipMemcpy(dp->d_words, dp->plan.words.data(), dp->plan.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc((void**)&dp->d_compact, dp->compact.words.size() * sizeof(uint32_t)));
+    HIPCHK(h, hipMemcpy(dp->d_compact, dp->compact.words.data(), dp->compact.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    dp->r3_lds = dp->compact.lds_bytes(dp->plan.k);
+    if (dp->r3_lds > h->max_r3_lds_prepared) {
+      HIPCHK(h, prepare_circuit_r3_kernel(dp->r3_lds));
+      h->max_r3_lds_prepared = dp->r3_lds;
+    }
+    dp->r3_workgroups = circuit_r3_workgroups_per_cu(1 << (dp->plan.k - 3), dp->r3_lds) * h->num_cus;
+    if (dp->r3_workgroups <= 0) return fail(h, BORNVI_ERR_HIP, "circuit_pass_r3_kernel: no workgroup fits a CU");
+    std::vector<uint32_t>().swap(dp->compact.words);
+    HIPCHK(h, hipDeviceSynchronize());
+    *out = dp.get();
+    h->plans[key] = std::move(dp);
+    return BORNVI_OK;
+  }
   HIPCHK(h, hipMalloc((void**)&dp->d_words, dp->plan.words.size() * sizeof(uint32_t)));
   HIPCHK(h, hipMemcpy(dp->d_words, dp->plan.words.data(), dp->plan.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (dp->plan.lds_bytes() > h->max_lds_prepared) {
@@ -157,7 +195,8 @@ void free_plan(DevPlan* dp) {
   if (!dp) return;
   if (dp->d_words) (void)hipFree(dp->d_words);
   if (dp->d_fast) (void)hipFree(dp->d_fast);
-  dp->d_words = dp->d_fast = nullptr;
+  if (dp->d_compact) (void)hipFree(dp->d_compact);
+  dp->d_words = dp->d_fast = dp->d_compact = nullptr;
   for (auto& stb : dp->share_cache)
     for (auto& c : stb->chunks) if (c.d_tab) (void)hipFree(c.d_tab);
   dp->share_cache.clear();
@@ -182,7 +221,24 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
   for (int i = 0; i < p.n_passes; ++i) {
     const bool last = (i == p.n_passes - 1);
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
-    if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
+    if (dp->d_compact) {
+      const int cus = h->circuit_cus > 0 ? h->circuit_cus : h->num_cus;
+      const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * cus : dp->r3_workgroups / h->num_cus * cus;
+      PrefixShare ps;
+      int nb = bc;
+      if (share) {
+        nb = share->active[i];
+        ps.fresh_begin = share->fresh[i];
+        ps.row_map = share->d_tab + share->bc;
+        ps.trash = trash;
+      }
+      HIPCHK(h, launch_circuit_pass_r3(dp->d_words, p.pass_off[i], dp->d_compact, dp->compact.pass_off[i], p.n, p.k, dp->r3_lds, nb, in,
+                                       out, final_probs, gates, gate_stride, wgs,
+                                       (((h->direct_stages >> 2) && (h->direct_stages >> 2) - 1 != i) ? 0 : (h->direct_stages & 3)) |
+                                           ((h->alternate_walk && (i & 1)) ? 4 : 0) |
+                                           ((in0 == nullptr && h->direct_stages == 3 && h->zero_support) ? 8 : 0),
+                                       ps, st));
+    } else if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
       const int cus = h->circuit_cus > 0 ? h->circuit_cus : h->num_cus;
       const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * cus : dp->fast_workgroups / h->num_cus * cus;
       PrefixShare ps;
@@ -288,7 +344,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   void* bufA = base + gates_bytes;
   void* bufB = base + gates_bytes + state_bytes;
   DEVICE_SCOPE(h);
-  if (shift_mode && h->prefix_share && p.n_passes > 1 && dp->d_fast && h->fast_path && dp->fast_workgroups > 0 &&
+  if (shift_mode && h->prefix_share && p.n_passes > 1 && (dp->d_compact || (dp->d_fast && h->fast_path && dp->fast_workgroups > 0)) &&
       batch > include_base) {
     // parameter-shift batch with prefix sharing: [gates | stateA | stateB | trash row]; each chunk carries the
     // base circuit in slot 0, so one slot of the capacity goes to it
@@ -476,9 +532,10 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;
   else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
   else if (!std::strcmp(name, "read_map")) o.read_map = value != 0;
+  else if (!std::strcmp(name, "reg_wires")) o.r = (int)value;
   else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
-  if (o.kmax < 4 || o.kmax > 13 || (o.kmulti != 0 && (o.kmulti < 4 || o.kmulti > 13)) || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 512 ||
-      (o.max_threads & (o.max_threads - 1)))
+  if (o.kmax < 4 || o.kmax > 13 || (o.kmulti != 0 && (o.kmulti < 4 || o.kmulti > 13)) || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 1024 ||
+      (o.max_threads & (o.max_threads - 1)) || (o.r != 3 && o.r != 4))
     return fail(h, BORNVI_ERR_INVALID, "option value out of range");
   h->opt = o;
   for (auto& kv : h->plans) free_plan(kv.second.get());
@@ -940,6 +997,8 @@ int bornvi_debug_circuit_stamps(bornvi_handle h, unsigned long long* out16) {
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
   PlanOptions opt;
   opt.read_map = (tile_bits & 0x100) != 0;       // (bit 8 of tile_bits: the planner's read_map option)
+  opt.r = (tile_bits & 0x200) ? 3 : 4;           // (bit 9: 3 register wires, the plan circuit_pass_r3_kernel runs)
+  if (opt.r == 4) opt.max_threads = 512;
   tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
   Plan p;
@@ -955,6 +1014,9 @@ long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uin
 
 int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, int* out, int cap) {
   PlanOptions opt;
+  opt.r = (tile_bits & 0x200) ? 3 : 4;
+  if (opt.r == 4) opt.max_threads = 512;
+  tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
   Plan p;
   std::string msg;
@@ -968,6 +1030,8 @@ long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits
                                     uint32_t* pass_off_out, int cap_passes) {
   PlanOptions opt;
   opt.read_map = (tile_bits & 0x100) != 0;
+  opt.r = (tile_bits & 0x200) ? 3 : 4;
+  if (opt.r == 4) opt.max_threads = 512;
   tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
   Plan p;
@@ -983,6 +1047,30 @@ long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits
   if (pass_off_out)
     for (int i = 0; i < cap_passes && i < (int)ft.pass_off.size(); ++i) pass_off_out[i] = ft.pass_off[i];
   return (long long)ft.words.size();
+}
+
+// Compact tables of the 3-register-wire plan (plan.hpp: CompactTables): returns the number of words (0: not eligible, -1:
+// no plan); every word was checked against its point evaluation by build_compact_tables.
+long long bornvi_plan_compact_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words,
+                                       uint32_t* pass_off_out, int cap_passes) {
+  PlanOptions opt;
+  opt.read_map = (tile_bits & 0x100) != 0;
+  opt.r = 3;
+  tile_bits &= 0xff;
+  if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
+  Plan p;
+  std::string msg;
+  const bool ok = (ansatz == -1) ? make_kron_plan(n, opt, p, msg) : make_plan(ansatz, n, layers, opt, p, msg);
+  if (!ok) return -1;
+  CompactTables ct;
+  if (!build_compact_tables(p, ct, msg) || ct.lds_bytes(p.k) > MAX_LDS_BYTES) return 0;
+  if (out) {
+    const size_t c = ct.words.size() < cap_words ? ct.words.size() : cap_words;
+    std::memcpy(out, ct.words.data(), c * sizeof(uint32_t));
+  }
+  if (pass_off_out)
+    for (int i = 0; i < cap_passes && i < (int)ct.pass_off.size(); ++i) pass_off_out[i] = ct.pass_off[i];
+  return (long long)ct.words.size();
 }
 
 }  // extern "C"

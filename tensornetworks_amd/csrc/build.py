@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 REPO = os.path.dirname(PKG)
-SOURCES = ["api.hip", "kernels_circuit.hip", "kernels_stein.hip", "kernels_batched.hip", "kernels_adjoint.hip", "plan.cpp"]
-HEADERS = [os.path.join(HERE, h) for h in ("plan.hpp", "kernels.hpp")] + [os.path.join(REPO, "include", "bornvi.h")]
+SOURCES = ["api.hip", "kernels_circuit.hip", "kernels_circuit8.hip", "kernels_stein.hip", "kernels_batched.hip", "kernels_adjoint.hip", "plan.cpp"]
+HEADERS = [os.path.join(HERE, h) for h in ("plan.hpp", "kernels.hpp", "circuit_dev.hpp")] + [os.path.join(REPO, "include", "bornvi.h")]
 OUT = os.path.join(PKG, "libbornvi_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE,

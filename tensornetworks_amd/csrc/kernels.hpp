@@ -31,6 +31,13 @@ hipError_t launch_circuit_pass_fast(const uint32_t* plan, uint32_t pass_off, con
                                     int n, int k, size_t lds, int batch, const void* in, void* out, double* probs,
                                     const double* gates, long long gate_stride, int max_workgroups, size_t lds_tab_off,
                                     size_t lds_mats2_off, int direct_mask, int dbg, const PrefixShare& share, hipStream_t st);
+// 8 amplitudes per thread, compact tables (kernels_circuit8.hip; plan.hpp: CompactTables)
+hipError_t prepare_circuit_r3_kernel(size_t lds_bytes);
+int circuit_r3_workgroups_per_cu(int threads, size_t lds);
+hipError_t launch_circuit_pass_r3(const uint32_t* plan, uint32_t pass_off, const uint32_t* ctab, uint32_t ct_off, int n, int k,
+                                  size_t lds, int batch, const void* in, void* out, double* probs, const double* gates,
+                                  long long gate_stride, int max_workgroups, int direct_mask, const PrefixShare& share,
+                                  hipStream_t st);
 hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st);
 hipError_t launch_cnot(double* state, int n, long long batch, int control, int target, hipStream_t st);
 hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st);

@@ -1,0 +1,384 @@
+// Persistent circuit pass kernel with 8 amplitudes per thread (3 register wires per stage) for gfx950.
+//
+// Same plan model, same tile <-> HBM maps and the same hand-counted vector-memory pipeline as circuit_pass_fast_kernel
+// (kernels_circuit.hip), re-cut for occupancy: a thread owns 2^3 amplitudes of the tile instead of 2^4,
+// so the stage body, the in-flight next tile and a matrix fit 128 VGPRs and FOUR waves per SIMD are resident (a 2^13
+// tile is one 1024-thread workgroup per CU, 2^11 tiles four 256-thread workgroups) instead of two.  With twice the threads per tile a
+// per-thread table row would be 4 KiB per stage and no longer fit beside the tile, so the tables come in their
+// COMPACT form (plan.hpp: CompactTables): every per-(tile row, thread) word is GF(2)-affine in (tile row, thread), i.e.
+// word = LANE[row][lane] ^ UNI[row][wave], 64 + 16 words per row in LDS.
+#include <hip/hip_runtime.h>
+
+#include "circuit_dev.hpp"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace bornvi {
+
+namespace {
+
+__device__ __forceinline__ uint32_t comb3(int j, const uint32_t (&B)[3]) {
+  return ((j & 1) ? B[0] : 0u) ^ ((j & 2) ? B[1] : 0u) ^ ((j & 4) ? B[2] : 0u);
+}
+
+// xor over bits j in [0, nbits) of v of cols[j] (GF(2)-linear phys-out address, plan.hpp: PW_OUT_COL)
+__device__ __forceinline__ uint32_t xor_cols16(uint32_t v, int nbits, const uint32_t* __restrict__ cols) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < nbits) o ^= (0u - ((v >> j) & 1u)) & cols[j];
+  return o;
+}
+
+template <int I>
+__device__ __forceinline__ void gate8(double (&ar)[8], double (&ai)[8], const double (&U)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j & (1 << I)) continue;
+    gate_pair_inplace(ar[j], ai[j], ar[j | (1 << I)], ai[j | (1 << I)], U);
+  }
+}
+
+__device__ __forceinline__ double flip_sign(double x, uint32_t bits, int j) {
+  const int sw = (int)((bits << (31 - j)) & 0x80000000u);
+  return __hiloint2double(__double2hiint(x) ^ sw, __double2loint(x));
+}
+
+__device__ __forceinline__ void sign8(uint32_t m, double (&ar)[8], double (&ai)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ar[j] = flip_sign(ar[j], m, j); ai[j] = flip_sign(ai[j], m, j); }
+}
+
+// the results of slot jj leave the thread: to LDS (IO 0 / 1), or straight to HBM (IO 2: 16 bytes, or |amp|^2 as 8 bytes)
+template <int IO, bool FIN>
+__device__ __forceinline__ void put_slot(double xr, double xi, int jj, char* __restrict__ lds, uint32_t wa0, const uint32_t (&WB)[3],
+                                         const uint32_t (&hb)[3], void* hbm_base) {
+  if (IO == 2) {
+    const uint32_t ha = wa0 ^ comb3(jj, hb);
+    if (FIN) async_store8(ha, xr * xr + xi * xi, hbm_base);
+    else async_store16(ha, (d2_t){xr, xi}, hbm_base);
+  } else {
+    *reinterpret_cast<double2*>(lds + (wa0 ^ comb3(jj, WB))) = make_double2(xr, xi);
+  }
+}
+
+// last gate of a stage with the write-back folded in: a pair's two results leave right behind its gate (spreads the
+// LDS writes / HBM stores over the gate and ends the amplitudes' live ranges early)
+template <int I, bool POST, int IO, bool FIN>
+__device__ __forceinline__ void gate8_last(double (&ar)[8], double (&ai)[8], const double (&U)[8], uint32_t post_bits,
+                                           char* __restrict__ lds, uint32_t wa0, const uint32_t (&WB)[3], const uint32_t (&hb)[3],
+                                           void* hbm_base) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j & (1 << I)) continue;
+    const int j1 = j | (1 << I);
+    gate_pair_inplace(ar[j], ai[j], ar[j1], ai[j1], U);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int jj = q ? j1 : j;
+      double xr = ar[jj], xi = ai[jj];
+      if (POST) { xr = flip_sign(xr, post_bits, jj); xi = flip_sign(xi, post_bits, jj); }
+      put_slot<IO, FIN>(xr, xi, jj, lds, wa0, WB, hb, hbm_base);
+    }
+  }
+}
+
+// One stage on the 8 amplitudes a thread owns; NG fused gates on register bits 0 .. NG-1, optional CZ sign products.
+// IO: 0 = LDS -> LDS; 1 = the amplitudes are the prefetched registers `v` (first stage of a pass, results to LDS);
+// 2 = LDS -> HBM (last stage of a pass).
+template <int NG, bool PRE, bool POST, int IO, bool FIN>
+__device__ __forceinline__ void stage8(char* __restrict__ lds, const double2* __restrict__ Us, uint32_t my_rw, uint32_t my_sg,
+                                       const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8], uint32_t hbm_off,
+                                       const uint32_t (&hb)[3], void* hbm_base, bool cross) {
+  double ar[8], ai[8];
+  if (IO == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ar[j] = v[j].x; ai[j] = v[j].y; }
+  } else {
+    const uint32_t ra0 = (my_rw & 0xffffu) << 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double2 x = *reinterpret_cast<const double2*>(lds + (ra0 ^ comb3(j, RB)));
+      ar[j] = x.x; ai[j] = x.y;
+    }
+    if (cross) {      // the read map took amplitudes from other threads' groups (plan.hpp: STAGE_CROSS_READ)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  if (PRE) sign8(my_sg & 0xffu, ar, ai);
+  uint32_t wa0 = (IO == 2) ? hbm_off : (my_rw >> 16) << 4;
+  double U[8];
+  if (NG > 1) { load_u(Us, U); gate8<0>(ar, ai, U); }
+  if (NG > 2) { load_u(Us + 4, U); gate8<1>(ar, ai, U); }
+  if (NG > 0) {
+    load_u(Us + 4 * (NG - 1), U);
+    asm volatile("" : "+v"(wa0));     // the write base is formed here, before the last gate
+    gate8_last<(NG > 0 ? NG - 1 : 0), POST, IO, FIN>(ar, ai, U, my_sg >> 16, lds, wa0, WB, hb, hbm_base);
+  } else {
+    asm volatile("" : "+v"(wa0));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double xr = ar[j], xi = ai[j];
+      if (POST) { xr = flip_sign(xr, my_sg >> 16, j); xi = flip_sign(xi, my_sg >> 16, j); }
+      put_slot<IO, FIN>(xr, xi, j, lds, wa0, WB, hb, hbm_base);
+    }
+  }
+}
+
+template <int IO, bool FIN>
+__device__ __forceinline__ void dispatch8(uint32_t kind, char* __restrict__ lds, const double2* __restrict__ Us, uint32_t my_rw,
+                                          uint32_t my_sg, const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8],
+                                          uint32_t hbm_off, const uint32_t (&hb)[3], void* hbm_base, bool cross) {
+#define BORNVI_ST8(NG, PRE, POST) \
+  case (NG) | ((PRE) << 3) | ((POST) << 4): stage8<NG, PRE, POST, IO, FIN>(lds, Us, my_rw, my_sg, RB, WB, v, hbm_off, hb, hbm_base, cross); break;
+#define BORNVI_ST8_NG(PRE, POST) BORNVI_ST8(0, PRE, POST) BORNVI_ST8(1, PRE, POST) BORNVI_ST8(2, PRE, POST) BORNVI_ST8(3, PRE, POST)
+  switch (kind) {
+    BORNVI_ST8_NG(0, 0)
+    BORNVI_ST8_NG(1, 0)
+    BORNVI_ST8_NG(0, 1)
+    BORNVI_ST8_NG(1, 1)
+    default: break;     // unreachable: build_compact_tables admits only these kinds
+  }
+#undef BORNVI_ST8_NG
+#undef BORNVI_ST8
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
+    const uint32_t* __restrict__ plan, uint32_t pass_off, const uint32_t* __restrict__ ctab, uint32_t ct_off,
+    const double2* __restrict__ in, double2* __restrict__ out, double* __restrict__ probs,
+    const double* __restrict__ gates, long long gate_stride, long long state_stride, long long total_tiles,
+    int direct_mask, PrefixShare share) {
+  extern __shared__ double2 tile[];
+  const uint32_t* __restrict__ P = plan + pass_off;
+  const uint32_t* __restrict__ C = ctab + ct_off;
+  const uint32_t flags = P[PW_FLAGS];
+  const int k = (int)P[PW_K], n = (int)P[PW_N];
+  uint32_t H[CH_WORDS];
+#pragma unroll
+  for (int i = 0; i < CH_WORDS; ++i) H[i] = C[i];
+  const uint32_t t = threadIdx.x, T = blockDim.x;     // T == 2^(k-3): 8 tile elements per thread
+  const uint32_t lane = t & 63u, wv = t >> 6;
+  const int kt = k - 3;
+  const uint32_t ksize = 1u << k;
+  const int gbits = n - k;
+  const int nstages = (int)H[CH_NSTAGES];
+  const uint32_t nrows = H[CH_NROWS], nsign = H[CH_NSIGN], NW = H[CH_NWAVES];
+  const uint32_t sign_any = H[CH_SIGN_PRE] | H[CH_SIGN_POST];
+  const bool init = flags & PASS_INIT, fin = flags & PASS_FINAL;
+  const int out_shift = fin ? 3 : 4;
+  // ---- LDS: tile | matrices (two buffers) | matrix-piece offsets | LANE rows | UNI rows of one tile row | MASK ----
+  char* __restrict__ lds = reinterpret_cast<char*>(tile);
+  const uint32_t npieces = (uint32_t)nstages * 12u;
+  double2* __restrict__ mats_a = tile + ksize;
+  double2* __restrict__ mats_b = mats_a + npieces;
+  uint32_t* __restrict__ mat_tab = reinterpret_cast<uint32_t*>(mats_b + npieces);
+  uint32_t* __restrict__ lane_tab = mat_tab + npieces;
+  uint32_t* __restrict__ uni_tab = lane_tab + nrows * 64u;
+  uint32_t* __restrict__ mask_tab = uni_tab + nrows * NW;
+  // (direct_mask: bit 0 / 1 allow the direct first / last stage; bit 2: walk the tiles backwards; bit 3: support of |0..0>)
+  const bool direct_in = (H[CH_DIRECT] & 1u) && !init && nstages > 0 && (direct_mask & 1);
+  const bool direct_out = (H[CH_DIRECT] & 2u) && nstages > 1 && (direct_mask & 2);
+  const uint32_t in_step[3] = {direct_in ? H[CH_IN_STEP_D] : H[CH_IN_STEP_N], direct_in ? H[CH_IN_STEP_D + 1] : H[CH_IN_STEP_N + 1],
+                               direct_in ? H[CH_IN_STEP_D + 2] : H[CH_IN_STEP_N + 2]};
+  const uint32_t fill_step[3] = {H[CH_FILL_STEP], H[CH_FILL_STEP + 1], H[CH_FILL_STEP + 2]};
+  const uint32_t drain_step[3] = {H[CH_DRAIN_STEP], H[CH_DRAIN_STEP + 1], H[CH_DRAIN_STEP + 2]};
+  const uint32_t out_step_d[3] = {H[CH_OUT_STEP_D], H[CH_OUT_STEP_D + 1], H[CH_OUT_STEP_D + 2]};
+  const uint32_t out_step_n[3] = {H[CH_OUT_STEP_N], H[CH_OUT_STEP_N + 1], H[CH_OUT_STEP_N + 2]};
+  const uint32_t row0 = (uint32_t)nstages + nsign;
+  const uint32_t row_in = row0 + (direct_in ? CR_IN_D : CR_IN_N);
+  const uint32_t row_out_d = row0 + CR_OUT_D, row_out_n = row0 + CR_OUT_N, row_slot = row0 + CR_SLOT;
+  const uint32_t* __restrict__ UNI = C + H[CH_UNI_OFF];
+  const uint32_t* __restrict__ MASK = C + H[CH_MASK_OFF];
+  // tile-row independent tables -> LDS (trip -1 already reads them for the first prefetch)
+  for (uint32_t i = t; i < nrows * 64u; i += T) lane_tab[i] = C[H[CH_LANE_OFF] + i];
+  for (uint32_t i = t; i < npieces; i += T) mat_tab[i] = C[H[CH_MAT_OFF] + i];
+  __syncthreads();
+
+  d2_t v[8];                // amplitudes of the NEXT tile (in flight during the current tile's stages)
+  d2_t mp;                  // its piece of the matrices
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (d2_t){0.0, 0.0};
+  mp = (d2_t){0.0, 0.0};
+  uint32_t g_pref = 0xffffffffu, in_uni = 0;   // tile row whose CR_IN uniform word is in in_uni
+  uint32_t g_tab = 0xffffffffu;                // tile row whose UNI / MASK rows are in LDS
+  uint32_t parity = 1;
+  const uint32_t* __restrict__ CS0 = C + CH_WORDS;
+
+#define BORNVI_RUN_STAGE8(S_, IO_)                                                                              \
+  do {                                                                                                          \
+    const uint32_t* __restrict__ CS_ = CS0 + (S_) * CS_WORDS;                                                   \
+    const uint32_t kind_ = CS_[CS_KIND];                                                                        \
+    const uint32_t RB_[3] = {CS_[CS_RB], CS_[CS_RB + 1], CS_[CS_RB + 2]};                                       \
+    const uint32_t WB_[3] = {CS_[CS_WB], CS_[CS_WB + 1], CS_[CS_WB + 2]};                                       \
+    const uint32_t rw_ = lane_tab[(uint32_t)(S_) * 64u + lane] ^ uni_tab[(uint32_t)(S_) * NW + wv];             \
+    uint32_t sg_ = 0;                                                                                           \
+    if (kind_ >> 3) {                                                                                           \
+      const uint32_t sr_ = (uint32_t)__popc(sign_any & ((1u << (S_)) - 1u));                                    \
+      sg_ = lane_tab[((uint32_t)nstages + sr_) * 64u + lane] ^ uni_tab[((uint32_t)nstages + sr_) * NW + wv];    \
+      const uint32_t mk_ = mask_tab[sr_ * NW + wv];                                                             \
+      sg_ ^= (0u - ((uint32_t)__popc(lane & (mk_ & 0xffu)) & 1u)) & 0x0000ffffu;                                \
+      sg_ ^= (0u - ((uint32_t)__popc(lane & (mk_ >> 8)) & 1u)) & 0xffff0000u;                                   \
+    }                                                                                                           \
+    const uint32_t ho_ = (IO_) == 2 ? (lane_tab[row_out_d * 64u + lane] ^ uni_tab[row_out_d * NW + wv]) : 0u;   \
+    if ((IO_) == 2 && fin)                                                                                      \
+      dispatch8<IO_, true>(kind_, lds, mats + (S_) * 12, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u); \
+    else                                                                                                        \
+      dispatch8<IO_, false>(kind_, lds, mats + (S_) * 12, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u); \
+  } while (0)
+
+  const long long walk_flip = total_tiles - 1;
+  const bool walk_rev = (direct_mask & 4) != 0;
+  const bool zskip = init && gbits > 0 && total_tiles < (1ll << 31);
+  const uint32_t zinfo = (direct_mask & 8) ? H[CH_ZINFO] : 0u;
+  const uint32_t zgmask = zskip ? zinfo : 0u;
+  const uint32_t zslots = (!init && direct_in) ? (zinfo & 0xffu) : 0u;
+  const uint32_t zs_nb = (uint32_t)(total_tiles >> gbits), zs_gm1 = (1u << gbits) - 1u;
+  for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x, parity ^= 1u) {
+    const bool real = Scur >= 0;
+    const long long Snext = Scur + gridDim.x;
+    const bool has_next = Snext < total_tiles;
+    long long Tcur, Tnext;
+    if (zskip) {     // INIT pass: the one non-zero tile of every circuit first, spread over all workgroups, then the zero tiles
+      const uint32_t sc = (uint32_t)(real ? Scur : 0), sn = (uint32_t)(has_next ? Snext : 0);
+      const uint32_t bc_ = sc < zs_nb ? sc : (sc - zs_nb) / zs_gm1, bn_ = sn < zs_nb ? sn : (sn - zs_nb) / zs_gm1;
+      Tcur = sc < zs_nb ? ((long long)sc << gbits) : (((long long)bc_ << gbits) | (1u + (sc - zs_nb - bc_ * zs_gm1)));
+      Tnext = sn < zs_nb ? ((long long)sn << gbits) : (((long long)bn_ << gbits) | (1u + (sn - zs_nb - bn_ * zs_gm1)));
+    } else {
+      Tcur = walk_rev ? walk_flip - Scur : Scur;
+      Tnext = walk_rev ? walk_flip - Snext : Snext;
+    }
+    if (!real && !has_next) break;
+    const uint32_t g = real ? (uint32_t)(Tcur & ((1ll << gbits) - 1)) : 0u;
+    const long long b = real ? (Tcur >> gbits) : 0;
+    const bool zero_tile = zskip && real && g != 0u;
+    const bool noop_tile = zero_tile && (g & zgmask) != 0u;
+    const bool next_zero = zskip && has_next && (Tnext & ((1ll << gbits) - 1)) != 0;
+    double2* __restrict__ mats = parity ? mats_b : mats_a;
+    double2* __restrict__ mats_next = parity ? mats_a : mats_b;
+    double2* dst = out + b * state_stride;
+    double* pdst = probs + (b << n);
+    if (fin && share.row_map) {
+      const int row = share.row_map[b];
+      pdst = row < 0 ? share.trash : probs + ((long long)row << n);
+    }
+    void* hbm_base = fin ? (void*)pdst : (void*)dst;
+    if (real) {
+      // the tile has arrived in registers: all but this wave's 8 tile-out stores are done
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i]));
+      if (init) {
+        if (!zero_tile)
+          for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
+      } else if (!direct_in) {
+        const uint32_t slot_t = (lane_tab[row_slot * 64u + lane] ^ uni_tab[row_slot * NW + wv]) & 0xffffu;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tile[slot_t ^ comb3(i, fill_step)] = make_double2(v[i].x, v[i].y);
+      }
+      if (direct_in) BORNVI_RUN_STAGE8(0, 1);
+      asm volatile("" ::: "memory");
+    }
+    // ---- the registers are free: the next tile starts its trip from HBM now (the only load site) ----
+    if (has_next) {
+      const uint32_t gn_ = (uint32_t)(Tnext & ((1ll << gbits) - 1));
+      const long long bn_ = Tnext >> gbits;
+      uint32_t tt_ = t;
+      asm volatile("" : "+v"(tt_));   // (nothing derived from the thread id is hoisted out of the loop)
+      if (!init && gn_ != g_pref) {   // rare: compiler-tracked load, waited for inside this branch
+        g_pref = gn_;
+        in_uni = UNI[((size_t)gn_ * nrows + row_in) * NW + (tt_ >> 6)];
+      }
+      if (tt_ < npieces && !next_zero) async_load16(mp, mat_tab[tt_], gates + bn_ * gate_stride);
+      if (!init) {
+        const uint32_t base_ = lane_tab[row_in * 64u + (tt_ & 63u)] ^ in_uni;
+        const double2* src_ = in + (bn_ >= share.fresh_begin ? 0ll : bn_) * state_stride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (!((zslots >> i) & 1u)) async_load16(v[i], base_ ^ comb3(i, in_step), src_);
+      }
+    }
+    if (real) {
+      __syncthreads();                          // the tile (or the first stage's result) is in LDS
+      for (int s = direct_in ? 1 : 0; s < (zero_tile ? 0 : nstages); ++s) {
+        if (s == nstages - 1 && direct_out) {
+          BORNVI_RUN_STAGE8(s, 2);
+        } else {
+          BORNVI_RUN_STAGE8(s, 0);
+          __syncthreads();
+        }
+      }
+      // ---- tile out: exactly 8 vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
+      if (noop_tile) {
+      } else if (zero_tile) {
+        const uint32_t off0 = (xor_cols16(t, kt, P + PW_OUT_COL) ^ xor_cols16(g, gbits, P + PW_OUT_GCOL)) << out_shift;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t off = off0 ^ comb3(i, out_step_n);
+          if (fin) async_store8(off, 0.0, pdst);
+          else async_store16(off, (d2_t){0.0, 0.0}, dst);
+        }
+      } else if (!direct_out) {
+        const uint32_t slot_t = (lane_tab[row_slot * 64u + lane] ^ uni_tab[row_slot * NW + wv]) >> 16;
+        const uint32_t off0 = lane_tab[row_out_n * 64u + lane] ^ uni_tab[row_out_n * NW + wv];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const double2 x = tile[slot_t ^ comb3(i, drain_step)];
+          const uint32_t off = off0 ^ comb3(i, out_step_n);
+          if (fin) async_store8(off, x.x * x.x + x.y * x.y, pdst);
+          else async_store16(off, (d2_t){x.x, x.y}, dst);
+        }
+      }
+    }
+    if (!has_next) break;
+    // ---- UNI / MASK rows of the NEXT tile's row -> LDS (the launcher makes the grid a multiple of the tiles per state
+    // whenever it can, so this runs once, in trip -1; compiler-tracked loads).  All stages of the current tile are done. ----
+    {
+      const uint32_t gnx = (uint32_t)(Tnext & ((1ll << gbits) - 1));
+      if (gnx != g_tab && !(zskip && gnx != 0u)) {
+        g_tab = gnx;
+        if (real) __syncthreads();            // (a slower wave may still be reading the rows of the current tile row)
+        for (uint32_t i = t; i < nrows * NW; i += T) uni_tab[i] = UNI[(size_t)gnx * nrows * NW + i];
+        for (uint32_t i = t; i < nsign * NW; i += T) mask_tab[i] = MASK[(size_t)gnx * nsign * NW + i];
+      }
+    }
+    // ---- the next tile's matrices (the oldest loads in flight) -> the other buffer ----
+    if (!real) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (init || zslots) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (fewer than 8 loads in flight: all but the stores)
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("" : "+v"(mp));
+    if (t < npieces) mats_next[t] = make_double2(mp.x, mp.y);
+    __syncthreads();   // the tile is overwritten by the next trip; its matrices and table rows are in place
+  }
+#undef BORNVI_RUN_STAGE8
+}
+
+hipError_t prepare_circuit_r3_kernel(size_t lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_r3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds_bytes);
+}
+
+int circuit_r3_workgroups_per_cu(int threads, size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_r3_kernel, threads, lds) != hipSuccess) return 0;
+  return nb;
+}
+
+hipError_t launch_circuit_pass_r3(const uint32_t* plan, uint32_t pass_off, const uint32_t* ctab, uint32_t ct_off, int n, int k,
+                                  size_t lds, int batch, const void* in, void* out, double* probs, const double* gates,
+                                  long long gate_stride, int max_workgroups, int direct_mask, const PrefixShare& share,
+                                  hipStream_t st) {
+  const long long total_tiles = (long long)batch << (n - k);
+  if (total_tiles == 0) return hipSuccess;
+  long long wgs = (max_workgroups > 0 && total_tiles > max_workgroups) ? max_workgroups : total_tiles;
+  const long long per_state = 1ll << (n - k);
+  if (wgs > per_state) wgs -= wgs % per_state;      // a workgroup keeps its tile row: its table rows stay in LDS
+  circuit_pass_r3_kernel<<<dim3((unsigned)wgs), dim3(1u << (k - 3)), lds, st>>>(
+      plan, pass_off, ctab, ct_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles,
+      direct_mask, share);
+  return hipGetLastError();
+}
+
+}  // namespace bornvi

@@ -373,6 +373,9 @@ bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& plan
     PlanOptions o11 = opt, o13 = opt;
     o11.kmulti = 11;
     o13.kmulti = 13;
+    // (3 register wires: 2^13 tiles, one 1024-thread workgroup per CU; the caller checks the compact tables' eligibility
+    // and falls back to the 4-wire plan otherwise)
+    if (opt.r == 3) return build_plan(spec, o13, plan, msg);
     Plan p13;
     std::string m13;
     if (build_plan(spec, o13, p13, m13)) {
@@ -846,14 +849,17 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
 bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
   out.words.clear(); out.pass_off.clear(); out.any_sign = false; out.max_tab_rows = 1;
   const int n = plan.n, k = plan.k;
-  if (plan.r != 4 || k < 10 || plan.threads != (1 << (k - 4)) || n - k > 16) return false;
-  const int kt = k - 4;
-  const size_t per_stage = (size_t)1 << (n - 4);
+  const int r = plan.r;
+  if ((r != 4 && r != 3) || k < (r == 4 ? 10 : 9) || plan.threads != (1 << (k - r)) || n - k > 16) return false;
+  out.r = r;
+  const int kt = k - r;
+  const int nslots = 1 << r;
+  const size_t per_stage = (size_t)1 << (n - r);
   size_t total = 0;
   for (int i = 0; i < plan.n_passes; ++i) {
     const uint32_t* P = plan.words.data() + plan.pass_off[i];
     const uint32_t nst = P[PW_NSTAGES];
-    if (nst > (uint32_t)MAX_STAGES || nst * 16u > (uint32_t)plan.threads) return false;   // one matrix piece per thread
+    if (nst > (uint32_t)MAX_STAGES || nst * 4u * (uint32_t)r > (uint32_t)plan.threads) return false;   // one matrix piece per thread
     bool any_sign = false;
     const uint32_t* S = P + PW_STAGES;
     for (uint32_t s = 0; s < nst; ++s) { if ((S[0] >> 8) & (STAGE_SIGN_PRE | STAGE_SIGN_POST)) any_sign = true; S += S[0] >> 16; }
@@ -891,28 +897,28 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
     const uint32_t* S = P + PW_STAGES;
     for (uint32_t s = 0; s < nst; ++s) {
       const uint32_t hdr = S[0];
-      if ((hdr & 0xffu) != 4u) { out.words.clear(); out.pass_off.clear(); return false; }
+      if ((hdr & 0xffu) != (uint32_t)r) { out.words.clear(); out.pass_off.clear(); return false; }
       const uint32_t sflags = (hdr >> 8) & 0xffu, nwords = hdr >> 16, rho = S[1];
       uint32_t* FS = W.data() + hbase + FH_WORDS + (size_t)s * FS_WORDS;
       FS[FS_FI01] = S[6]; FS[FS_FI23] = S[7];
       {   // gates must occupy register bits 0 .. ng-1 (stage planner: U-carrying wires first)
         const uint32_t fi[4] = {S[6] & 0xffffu, S[6] >> 16, S[7] & 0xffffu, S[7] >> 16};
         uint32_t ng = 0;
-        while (ng < 4 && fi[ng] != 0xffffu) ++ng;
+        while (ng < (uint32_t)r && fi[ng] != 0xffffu) ++ng;
         for (uint32_t b = ng; b < 4; ++b)
           if (fi[b] != 0xffffu) { out.words.clear(); out.pass_off.clear(); return false; }
         FS[FS_KIND] = ng | ((sflags & STAGE_SIGN_PRE) ? 8u : 0u) | ((sflags & STAGE_SIGN_POST) ? 16u : 0u);
         FS[FS_CROSS] = (sflags & STAGE_CROSS_READ) ? 1u : 0u;
         if (!fast_stage_kind_supported(FS[FS_KIND])) { out.words.clear(); out.pass_off.clear(); return false; }
       }
-      for (int b = 0; b < 4; ++b) { FS[FS_RB + b] = S[16 + (1 << b)] << 4; FS[FS_WB + b] = S[32 + (1 << b)] << 4; }
-      for (int j = 0; j < 16; ++j) {   // the slot offsets must be linear in the slot number
+      for (int b = 0; b < r; ++b) { FS[FS_RB + b] = S[16 + (1 << b)] << 4; FS[FS_WB + b] = S[32 + (1 << b)] << 4; }
+      for (int j = 0; j < nslots; ++j) {   // the slot offsets must be linear in the slot number
         uint32_t lr = 0, lw = 0;
-        for (int b = 0; b < 4; ++b) if (j >> b & 1) { lr ^= S[16 + (1 << b)]; lw ^= S[32 + (1 << b)]; }
+        for (int b = 0; b < r; ++b) if (j >> b & 1) { lr ^= S[16 + (1 << b)]; lw ^= S[32 + (1 << b)]; }
         if (lr != S[16 + j] || lw != S[32 + j]) { out.words.clear(); out.pass_off.clear(); return false; }
       }
-      uint32_t sri[4], rpos[4];
-      for (int b = 0; b < 4; ++b) { rpos[b] = (rho >> (8 * b)) & 0xffu; sri[b] = lds_swizzle(1u << rpos[b]); }
+      uint32_t sri[4] = {0, 0, 0, 0}, rpos[4] = {0, 0, 0, 0};
+      for (int b = 0; b < r; ++b) { rpos[b] = (rho >> (8 * b)) & 0xffu; sri[b] = lds_swizzle(1u << rpos[b]); }
       const uint32_t* Qpre = (sflags & STAGE_SIGN_PRE) ? S + STAGE_HDR_WORDS : nullptr;
       const uint32_t* Qpost = (sflags & STAGE_SIGN_POST) ? S + STAGE_HDR_WORDS + (Qpre ? SIGNQ_WORDS : 0) : nullptr;
       const uint32_t* tab = S + STAGE_HDR_WORDS + (Qpre ? SIGNQ_WORDS : 0) + (Qpost ? SIGNQ_WORDS : 0);
@@ -930,7 +936,7 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
           const uint32_t pb = tab[t] & 0xffffu, base = tab[t] >> 16;
           const uint32_t e = base | (g << k);
           uint32_t lflip = 0, sflip = 0, e2 = e;
-          for (int b = 0; b < 4; ++b) {
+          for (int b = 0; b < r; ++b) {
             if (parity(e & S[8 + b])) lflip ^= sri[b];
             if (parity(e & S[12 + b])) { sflip ^= sri[b]; e2 |= 1u << rpos[b]; }
           }
@@ -963,8 +969,8 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
         W.resize(W.size() + per_stage, 0);
         const uint32_t* RW0 = W.data() + rw_base;
         bool ok = true;
-        uint32_t basis[4];
-        for (int b = 0; b < 4; ++b) basis[b] = phys_u(inv[W[hbase + FH_WORDS + FS_RB + b] >> 4]) << 4;
+        uint32_t basis[4] = {0, 0, 0, 0};
+        for (int b = 0; b < r; ++b) basis[b] = phys_u(inv[W[hbase + FH_WORDS + FS_RB + b] >> 4]) << 4;
         for (uint32_t g = 0; g < ngl && ok; ++g) {
           uint32_t gslot = 0, gphys = 0;
           for (int m = 0; m < n - k; ++m) if (g >> m & 1) { gslot ^= thalf(PW_IN_GMASK, m); gphys |= 1u << tbyte(PW_IN_GPHYS, m); }
@@ -988,10 +994,10 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
             if (seen != (lanes == 64 ? ~0ull : ((1ull << lanes) - 1ull))) ok = false;
           }
         }
-        for (int b = 0; b < 4; ++b) if (basis[b] & ((16u << std::min<uint32_t>(P[PW_LO_IN], 6u)) - 1u)) ok = false;   // slot offsets must not move inside the run
+        for (int b = 0; b < r; ++b) if (basis[b] & ((16u << std::min<uint32_t>(P[PW_LO_IN], 6u)) - 1u)) ok = false;   // slot offsets must not move inside the run
         if (ok) {
           W[hbase + FH_IN_TAB] = tab;
-          for (int b = 0; b < 4; ++b) W[hbase + FH_IN_BASIS + b] = basis[b];
+          for (int b = 0; b < r; ++b) W[hbase + FH_IN_BASIS + b] = basis[b];
           // Support of |0..0>.  After an INIT pass 0 the state is zero wherever one of pass 0's tile-index wires is 1
           // (its gates act inside a tile).  If this is pass 1 and those wires' address bits reach the direct first
           // stage only through the SLOT offsets (never through a thread's base), slot j of every thread is known to be
@@ -1006,13 +1012,13 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
             uint32_t in_base = 0, in_slot = 0;
             for (uint32_t g = 0; g < ngl; ++g)
               for (uint32_t t = 0; t < (1u << kt2); ++t) in_base |= W[tab + ((size_t)g << kt2) + t] & zbits;
-            for (int b = 0; b < 4; ++b) in_slot |= basis[b] & zbits;
+            for (int b = 0; b < r; ++b) in_slot |= basis[b] & zbits;
             const uint32_t zs = in_slot & ~in_base;               // zero-wire bits that only slots carry
             if (zs) {
               uint32_t zslots = 0;
-              for (int j = 0; j < 16; ++j) {
+              for (int j = 0; j < nslots; ++j) {
                 uint32_t off = 0;
-                for (int b = 0; b < 4; ++b) if (j >> b & 1) off ^= basis[b];
+                for (int b = 0; b < r; ++b) if (j >> b & 1) off ^= basis[b];
                 if (off & zs) zslots |= 1u << j;
               }
               uint32_t gmask0 = 0;
@@ -1037,8 +1043,8 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
         W.resize(W.size() + per_stage, 0);
         const uint32_t* RWL = W.data() + rw_base + (size_t)(nst - 1) * per_stage;
         bool ok = (n + sh) <= 32;
-        uint32_t basis[4];
-        for (int b = 0; b < 4; ++b) basis[b] = phys_v(inv[W[hbase + FH_WORDS + (size_t)(nst - 1) * FS_WORDS + FS_WB + b] >> 4]) << sh;
+        uint32_t basis[4] = {0, 0, 0, 0};
+        for (int b = 0; b < r; ++b) basis[b] = phys_v(inv[W[hbase + FH_WORDS + (size_t)(nst - 1) * FS_WORDS + FS_WB + b] >> 4]) << sh;
         const uint32_t lanes_o = 1u << std::min<uint32_t>(P[PW_LO_OUT], 6u);
         const uint32_t runmask = (lanes_o << sh) - 1u;
         if (P[PW_LO_OUT] < 4u && !(pflags & PASS_FINAL)) ok = false;
@@ -1070,13 +1076,319 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out) {
         }
         if (ok) {
           W[hbase + FH_OUT_TAB] = tab;
-          for (int b = 0; b < 4; ++b) W[hbase + FH_OUT_BASIS + b] = basis[b];
+          for (int b = 0; b < r; ++b) W[hbase + FH_OUT_BASIS + b] = basis[b];
         } else {
           W.resize(tab);
         }
       }
     }
   }
+  return true;
+}
+
+
+// ---- compact tables (plan.hpp: CompactTables; kernels_circuit8.hip) --------------------------------------------------
+// Point evaluation of the same quantities build_fast_tables tabulates, then their lane / wave / tile-row decomposition,
+// checked word by word against the point evaluation.
+namespace {
+inline uint32_t par32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 1u; }
+
+struct StageEval {
+  const uint32_t* S = nullptr;      // stage header (plan words)
+  const uint32_t* tab = nullptr;    // per-thread base table: lds_swizzle(base_t) | base_t << 16
+  const uint32_t* Qpre = nullptr;
+  const uint32_t* Qpost = nullptr;
+  uint32_t sri[3] = {0, 0, 0}, rpos[3] = {0, 0, 0};
+  int k = 0, n = 0;
+  // read slot | write slot << 16 of thread t in tile row g; e / e2: the extended indices the signs are evaluated on
+  uint32_t rw(uint32_t g, uint32_t t, uint32_t* e_out = nullptr, uint32_t* e2_out = nullptr) const {
+    const uint32_t pb = tab[t] & 0xffffu, base = tab[t] >> 16;
+    const uint32_t e = base | (g << k);
+    uint32_t lflip = 0, sflip = 0, e2 = e;
+    for (int b = 0; b < 3; ++b) {
+      if (par32(e & S[8 + b])) lflip ^= sri[b];
+      if (par32(e & S[12 + b])) { sflip ^= sri[b]; e2 |= 1u << rpos[b]; }
+    }
+    for (int p2 = 0; p2 < k; ++p2)
+      if (S[48 + p2] && par32(e & S[48 + p2])) lflip ^= lds_swizzle(1u << p2);
+    if (e_out) *e_out = e;
+    if (e2_out) *e2_out = e2;
+    return (pb ^ lflip) | ((pb ^ sflip) << 16);
+  }
+  uint32_t sign_bits(const uint32_t* Q, uint32_t e) const {
+    uint32_t acc = 0;
+    for (int q = 0; q < n; ++q) acc ^= ((e >> q) & 1u) & par32(e & Q[q]);
+    uint32_t m = 0;
+    for (int j = 0; j < 16; ++j) m |= (((Q[48] >> j) ^ acc ^ par32(e & Q[32 + j])) & 1u) << j;
+    return m;
+  }
+  uint32_t sg(uint32_t g, uint32_t t) const {
+    uint32_t e, e2;
+    (void)rw(g, t, &e, &e2);
+    return (Qpre ? sign_bits(Qpre, e) : 0u) | ((Qpost ? sign_bits(Qpost, e2) : 0u) << 16);
+  }
+};
+}  // namespace
+
+bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg) {
+  out = CompactTables();
+  const int n = plan.n, k = plan.k, r = plan.r;
+  if (r != 3) { msg = "compact tables: the plan must have 3 register wires"; return false; }
+  if (k < 9 || plan.threads != (1 << (k - 3)) || n - k > 16 || n > 27) { msg = "compact tables: tile below 2^9 or state too large"; return false; }
+  const int kt = k - 3, gbits = n - k;
+  const uint32_t T = 1u << kt, NW = T / 64u, ngl = 1u << gbits, ksize = 1u << k;
+  std::vector<uint32_t>& W = out.words;
+  auto fail = [&](const std::string& m) { msg = "compact tables: " + m; out = CompactTables(); return false; };
+  for (int i = 0; i < plan.n_passes; ++i) {
+    const uint32_t* P = plan.words.data() + plan.pass_off[i];
+    const uint32_t nst = P[PW_NSTAGES];
+    if (nst > (uint32_t)MAX_STAGES || nst * 12u > T) return fail("more matrix pieces than threads");
+    auto tbyte = [&](int table, int j) { return (P[table + (j >> 2)] >> (8 * (j & 3))) & 0xffu; };
+    auto thalf = [&](int table, int j) { return (P[table + (j >> 1)] >> (16 * (j & 1))) & 0xffffu; };
+    const uint32_t pflags = P[PW_FLAGS];
+    const int out_shift = (pflags & PASS_FINAL) ? 3 : 4;
+    // ---- stages ----
+    std::vector<StageEval> SE(nst);
+    uint32_t sign_pre = 0, sign_post = 0;
+    {
+      const uint32_t* S = P + PW_STAGES;
+      for (uint32_t s = 0; s < nst; ++s) {
+        const uint32_t hdr = S[0], sflags = (hdr >> 8) & 0xffu, rho = S[1];
+        if ((hdr & 0xffu) != 3u) return fail("a stage with r != 3");
+        StageEval& E = SE[s];
+        E.S = S; E.k = k; E.n = n;
+        for (int b = 0; b < 3; ++b) { E.rpos[b] = (rho >> (8 * b)) & 0xffu; E.sri[b] = lds_swizzle(1u << E.rpos[b]); }
+        E.Qpre = (sflags & STAGE_SIGN_PRE) ? S + STAGE_HDR_WORDS : nullptr;
+        E.Qpost = (sflags & STAGE_SIGN_POST) ? S + STAGE_HDR_WORDS + (E.Qpre ? SIGNQ_WORDS : 0) : nullptr;
+        E.tab = S + STAGE_HDR_WORDS + (E.Qpre ? SIGNQ_WORDS : 0) + (E.Qpost ? SIGNQ_WORDS : 0);
+        if (E.Qpre) sign_pre |= 1u << s;
+        if (E.Qpost) sign_post |= 1u << s;
+        S += hdr >> 16;
+      }
+    }
+    const uint32_t sign_any = sign_pre | sign_post;
+    const uint32_t nsign = (uint32_t)__builtin_popcount(sign_any);
+    const uint32_t nrows = nst + nsign + CR_EXTRA;
+    const uint32_t hb = (uint32_t)W.size();
+    out.pass_off.push_back(hb);
+    W.resize(hb + CH_WORDS + (size_t)nst * CS_WORDS, 0);
+    W[hb + CH_NSTAGES] = nst; W[hb + CH_NROWS] = nrows; W[hb + CH_NSIGN] = nsign;
+    W[hb + CH_SIGN_PRE] = sign_pre; W[hb + CH_SIGN_POST] = sign_post; W[hb + CH_NWAVES] = NW;
+    for (uint32_t s = 0; s < nst; ++s) {
+      const uint32_t* S = SE[s].S;
+      const uint32_t sflags = (S[0] >> 8) & 0xffu;
+      const uint32_t fi[4] = {S[6] & 0xffffu, S[6] >> 16, S[7] & 0xffffu, S[7] >> 16};
+      uint32_t ngt = 0;
+      while (ngt < 3 && fi[ngt] != 0xffffu) ++ngt;
+      for (uint32_t b = ngt; b < 4; ++b) if (fi[b] != 0xffffu) return fail("gates not on register bits 0 .. ng-1");
+      uint32_t* CS = W.data() + hb + CH_WORDS + (size_t)s * CS_WORDS;
+      CS[CS_KIND] = ngt | ((sflags & STAGE_SIGN_PRE) ? 8u : 0u) | ((sflags & STAGE_SIGN_POST) ? 16u : 0u);
+      CS[CS_CROSS] = (sflags & STAGE_CROSS_READ) ? 1u : 0u;
+      for (int b = 0; b < 3; ++b) { CS[CS_RB + b] = S[16 + (1 << b)] << 4; CS[CS_WB + b] = S[32 + (1 << b)] << 4; }
+      for (int j = 0; j < 8; ++j) {
+        uint32_t lr = 0, lw = 0;
+        for (int b = 0; b < 3; ++b) if (j >> b & 1) { lr ^= S[16 + (1 << b)]; lw ^= S[32 + (1 << b)]; }
+        if (lr != S[16 + j] || lw != S[32 + j]) return fail("slot offsets not linear in the slot number");
+      }
+    }
+    // ---- matrix pieces: piece p = (stage, register bit, 16-byte quarter) ----
+    W[hb + CH_MAT_OFF] = (uint32_t)W.size() - hb;
+    for (uint32_t p2 = 0; p2 < nst * 12u; ++p2) {
+      const uint32_t st = p2 / 12u, rb = (p2 % 12u) >> 2;
+      const uint32_t w = P[PW_MATS + 2 * st + (rb >> 1)];
+      const uint32_t f = (rb & 1u) ? (w >> 16) : (w & 0xffffu);
+      W.push_back(((f != 0xffffu ? f : 0u) * 4u + (p2 & 3u)) << 4);
+    }
+    // ---- ordinary tile fill / drain steps ----
+    for (int m = 0; m < 3; ++m) {
+      W[hb + CH_IN_STEP_N + m] = 16u << tbyte(PW_IN_PHYS, kt + m);
+      W[hb + CH_FILL_STEP + m] = thalf(PW_IN_MASK, kt + m);
+      W[hb + CH_DRAIN_STEP + m] = thalf(PW_OUT_MASK, kt + m);
+      W[hb + CH_OUT_STEP_N + m] = P[PW_OUT_COL + kt + m] << out_shift;
+    }
+    // ---- direct first / last stage: offsets and eligibility exactly as build_fast_tables ----
+    std::vector<uint32_t> inv_in, inv_out;
+    bool ok_in = false, ok_out = false;
+    uint32_t in_basis[3] = {0, 0, 0}, out_basis[3] = {0, 0, 0};
+    auto in_slot_lin = [&](uint32_t u) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (u >> j & 1) o ^= thalf(PW_IN_MASK, j); return o; };
+    auto in_phys_u = [&](uint32_t u) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (u >> j & 1) o |= 1u << tbyte(PW_IN_PHYS, j); return o; };
+    auto out_slot_lin = [&](uint32_t v) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (v >> j & 1) o ^= thalf(PW_OUT_MASK, j); return o; };
+    auto out_phys_v = [&](uint32_t v) { uint32_t o = 0; for (int j = 0; j < k; ++j) if (v >> j & 1) o ^= P[PW_OUT_COL + j]; return o; };
+    auto g_in = [&](uint32_t g, uint32_t& gslot, uint32_t& gphys) {
+      gslot = gphys = 0;
+      for (int m = 0; m < gbits; ++m) if (g >> m & 1) { gslot ^= thalf(PW_IN_GMASK, m); gphys |= 1u << tbyte(PW_IN_GPHYS, m); }
+    };
+    auto g_out = [&](uint32_t g, uint32_t& gslot, uint32_t& gphys) {
+      gslot = gphys = 0;
+      for (int m = 0; m < gbits; ++m) if (g >> m & 1) { gslot ^= thalf(PW_OUT_GMASK, m); gphys ^= P[PW_OUT_GCOL + m]; }
+    };
+    auto in_d = [&](uint32_t g, uint32_t t) {
+      uint32_t gslot, gphys;
+      g_in(g, gslot, gphys);
+      return (in_phys_u(inv_in[(SE[0].rw(g, t) & 0xffffu) ^ gslot]) | gphys) << 4;
+    };
+    auto out_d = [&](uint32_t g, uint32_t t) {
+      uint32_t gslot, gphys;
+      g_out(g, gslot, gphys);
+      return (out_phys_v(inv_out[(SE[nst - 1].rw(g, t) >> 16) ^ gslot]) ^ gphys) << out_shift;
+    };
+    if (nst > 0) {
+      const uint32_t f0 = (SE[0].S[0] >> 8) & 0xffu, fl = (SE[nst - 1].S[0] >> 8) & 0xffu;
+      if ((f0 & STAGE_FROM_HBM) && !(pflags & PASS_INIT)) {
+        inv_in.assign(ksize, 0);
+        for (uint32_t u = 0; u < ksize; ++u) inv_in[in_slot_lin(u)] = u;
+        for (int b = 0; b < 3; ++b) in_basis[b] = in_phys_u(inv_in[W[hb + CH_WORDS + CS_RB + b] >> 4]) << 4;
+        ok_in = P[PW_LO_IN] >= 4u;
+        const uint32_t lanes = 1u << std::min<uint32_t>(P[PW_LO_IN], 6u);
+        const uint32_t runmask = lanes * 16u - 1u;
+        std::vector<uint32_t> row(T);
+        for (uint32_t g = 0; g < ngl && ok_in; ++g) {
+          for (uint32_t t = 0; t < T; ++t) row[t] = in_d(g, t);
+          for (uint32_t t0 = 0; t0 < T && ok_in; t0 += lanes) {    // every group of 2^lo_in lanes loads one aligned run
+            const uint32_t base_run = row[t0] & ~runmask;
+            uint64_t seen = 0;
+            for (uint32_t l = 0; l < lanes; ++l) {
+              if ((row[t0 + l] & ~runmask) != base_run) ok_in = false;
+              seen |= 1ull << ((row[t0 + l] >> 4) & (lanes - 1u));
+            }
+            if (seen != (lanes == 64 ? ~0ull : ((1ull << lanes) - 1ull))) ok_in = false;
+          }
+        }
+        for (int b = 0; b < 3; ++b) if (in_basis[b] & ((16u << std::min<uint32_t>(P[PW_LO_IN], 6u)) - 1u)) ok_in = false;
+      }
+      if (fl & STAGE_TO_HBM) {
+        inv_out.assign(ksize, 0);
+        for (uint32_t v = 0; v < ksize; ++v) inv_out[out_slot_lin(v)] = v;
+        for (int b = 0; b < 3; ++b) out_basis[b] = out_phys_v(inv_out[W[hb + CH_WORDS + (size_t)(nst - 1) * CS_WORDS + CS_WB + b] >> 4]) << out_shift;
+        ok_out = (n + out_shift) <= 32;
+        const uint32_t lanes_o = 1u << std::min<uint32_t>(P[PW_LO_OUT], 6u);
+        const uint32_t runmask = (lanes_o << out_shift) - 1u;
+        if (P[PW_LO_OUT] < 4u && !(pflags & PASS_FINAL)) ok_out = false;
+        if ((pflags & PASS_FINAL) && P[PW_LO_OUT] < 3u) ok_out = false;
+        std::vector<uint32_t> row(T);
+        for (uint32_t g = 0; g < ngl && ok_out; ++g) {
+          for (uint32_t t = 0; t < T; ++t) row[t] = out_d(g, t);
+          for (uint32_t t0 = 0; t0 < T && ok_out; t0 += lanes_o) {
+            uint32_t runs[2] = {0, 0};
+            int nruns = 0;
+            uint64_t seen = 0;
+            for (uint32_t l = 0; l < lanes_o; ++l) {
+              const uint32_t o = row[t0 + l], rb = o & ~runmask;
+              int f = -1;
+              for (int q = 0; q < nruns; ++q) if (runs[q] == rb) f = q;
+              if (f < 0) { if (nruns == 2) { ok_out = false; break; } runs[nruns++] = rb; }
+              seen |= 1ull << ((o >> out_shift) & (lanes_o - 1u));
+            }
+            if (nruns > ((pflags & PASS_FINAL) ? 2 : 1)) ok_out = false;
+            if (seen != (lanes_o == 64 ? ~0ull : ((1ull << lanes_o) - 1ull))) ok_out = false;
+          }
+        }
+      }
+    }
+    W[hb + CH_DIRECT] = (ok_in ? 1u : 0u) | (ok_out ? 2u : 0u);
+    for (int b = 0; b < 3; ++b) { W[hb + CH_IN_STEP_D + b] = ok_in ? in_basis[b] : 0u; W[hb + CH_OUT_STEP_D + b] = ok_out ? out_basis[b] : 0u; }
+    // ---- support of |0..0> (see build_fast_tables: FH_ZINFO) ----
+    if (ok_in && i == 1 && (plan.words[plan.pass_off[0] + PW_FLAGS] & PASS_INIT) && plan.n_passes > 2) {
+      const uint32_t* P0 = plan.words.data() + plan.pass_off[0];
+      uint32_t zbits = 0;
+      for (int m = 0; m < gbits; ++m) zbits |= 16u << ((P0[PW_OUT_GPHYS + (m >> 2)] >> (8 * (m & 3))) & 0xffu);
+      uint32_t in_base = 0, in_slot = 0;
+      for (uint32_t g = 0; g < ngl; ++g)
+        for (uint32_t t = 0; t < T; ++t) in_base |= in_d(g, t) & zbits;
+      for (int b = 0; b < 3; ++b) in_slot |= in_basis[b] & zbits;
+      const uint32_t zs = in_slot & ~in_base;
+      if (zs) {
+        uint32_t zslots = 0;
+        for (int j = 0; j < 8; ++j) {
+          uint32_t off = 0;
+          for (int b = 0; b < 3; ++b) if (j >> b & 1) off ^= in_basis[b];
+          if (off & zs) zslots |= 1u << j;
+        }
+        uint32_t gmask0 = 0;
+        for (int m = 0; m < gbits; ++m)
+          if (zs & (16u << ((P0[PW_OUT_GPHYS + (m >> 2)] >> (8 * (m & 3))) & 0xffu))) gmask0 |= 1u << m;
+        W[hb + CH_ZINFO] = zslots;
+        W[out.pass_off[0] + CH_ZINFO] = gmask0;
+      }
+    }
+    // ---- rows: point evaluators ----
+    const uint32_t lo_in = P[PW_LO_IN];
+    auto row_eval = [&](uint32_t row, uint32_t g, uint32_t t) -> uint32_t {
+      if (row < nst) return SE[row].rw(g, t);
+      if (row < nst + nsign) {
+        uint32_t s = 0, seen = 0;
+        for (;; ++s) if ((sign_any >> s) & 1u) { if (seen == row - nst) break; ++seen; }
+        return SE[s].sg(g, t);
+      }
+      switch ((int)(row - nst - nsign)) {
+        case CR_IN_D: return ok_in ? in_d(g, t) : 0u;
+        case CR_OUT_D: return ok_out ? out_d(g, t) : 0u;
+        case CR_IN_N: {
+          uint32_t o = t & ((1u << lo_in) - 1u);
+          for (int j = (int)lo_in; j < kt; ++j) o |= ((t >> j) & 1u) << tbyte(PW_IN_PHYS, j);
+          for (int m = 0; m < gbits; ++m) o |= ((g >> m) & 1u) << tbyte(PW_IN_GPHYS, m);
+          return o << 4;
+        }
+        case CR_OUT_N: {
+          uint32_t o = 0;
+          for (int j = 0; j < kt; ++j) if (t >> j & 1) o ^= P[PW_OUT_COL + j];
+          for (int m = 0; m < gbits; ++m) if (g >> m & 1) o ^= P[PW_OUT_GCOL + m];
+          return o << out_shift;
+        }
+        default: {   // CR_SLOT
+          uint32_t a = 0, b2 = 0;
+          for (int j = 0; j < kt; ++j) if (t >> j & 1) { a ^= thalf(PW_IN_MASK, j); b2 ^= thalf(PW_OUT_MASK, j); }
+          for (int m = 0; m < gbits; ++m) if (g >> m & 1) { a ^= thalf(PW_IN_GMASK, m); b2 ^= thalf(PW_OUT_GMASK, m); }
+          return a | (b2 << 16);
+        }
+      }
+    };
+    // ---- LANE / UNI / MASK ----
+    const uint32_t lane_off = (uint32_t)W.size() - hb;
+    W.resize(W.size() + (size_t)nrows * 64, 0);
+    const uint32_t uni_off = (uint32_t)W.size() - hb;
+    W.resize(W.size() + (size_t)ngl * nrows * NW, 0);
+    const uint32_t mask_off = (uint32_t)W.size() - hb;
+    W.resize(W.size() + (size_t)ngl * (nsign ? nsign : 1u) * NW, 0);
+    W[hb + CH_LANE_OFF] = lane_off; W[hb + CH_UNI_OFF] = uni_off; W[hb + CH_MASK_OFF] = mask_off;
+    for (uint32_t row = 0; row < nrows; ++row) {
+      const bool is_sign = row >= nst && row < nst + nsign;
+      const uint32_t f00 = row_eval(row, 0, 0);
+      uint32_t* LANE = W.data() + hb + lane_off + (size_t)row * 64;
+      for (uint32_t l = 0; l < 64; ++l) LANE[l] = row_eval(row, 0, l);
+      for (uint32_t g = 0; g < ngl; ++g)
+        for (uint32_t w = 0; w < NW; ++w) {
+          const uint32_t fgw = row_eval(row, g, 64u * w);
+          W[hb + uni_off + ((size_t)g * nrows + row) * NW + w] = fgw ^ f00;
+          if (is_sign) {
+            uint32_t mpre = 0, mpost = 0;
+            for (int b = 0; b < 6; ++b) {
+              const uint32_t d = row_eval(row, g, 64u * w + (1u << b)) ^ LANE[1u << b] ^ fgw ^ f00;
+              mpre |= (d & 1u) << b;
+              mpost |= ((d >> 16) & 1u) << b;
+            }
+            W[hb + mask_off + ((size_t)g * nsign + (row - nst)) * NW + w] = mpre | (mpost << 8);
+          }
+        }
+      // check: every (g, t) when there are at most 2^22 of them, else all t of 64 tile rows spread over the range
+      const uint32_t gstep = ((size_t)ngl * T <= ((size_t)1 << 22)) ? 1u : ngl / 64u;
+      for (uint32_t g = 0; g < ngl; g += gstep)
+        for (uint32_t t = 0; t < T; ++t) {
+          const uint32_t l = t & 63u, w = t >> 6;
+          uint32_t v = LANE[l] ^ W[hb + uni_off + ((size_t)g * nrows + row) * NW + w];
+          if (is_sign) {
+            const uint32_t mk = W[hb + mask_off + ((size_t)g * nsign + (row - nst)) * NW + w];
+            if (par32(l & (mk & 0xffu))) v ^= 0x0000ffffu;
+            if (par32(l & (mk >> 8))) v ^= 0xffff0000u;
+          }
+          if (v != row_eval(row, g, t)) return fail("a table word is not affine in (tile row, thread): pass " + std::to_string(i) + " row " + std::to_string(row));
+        }
+    }
+    out.max_rows = std::max(out.max_rows, (int)nrows);
+    out.max_sign = std::max(out.max_sign, (int)nsign);
+    out.max_stages = std::max(out.max_stages, (int)nst);
+  }
+  if (W.size() >= (size_t)0x7fffffffu) return fail("tables too large");
   return true;
 }
 

@@ -133,9 +133,10 @@ struct PlanOptions {
   int kmulti = 0;    // tile bits when the state needs several tiles (n > kmax).  0 = by measurement on MI355X
                      // (DESIGN.md 4.1): 2^13 (one 512-thread workgroup per CU, the large-tile instantiation of the
                      // fast kernel) wherever the fast kernel can run it, else 2^11 (make_plan)
-  int r = 4;         // register wires per stage (2^4 amplitudes per thread)
+  int r = 4;         // register wires per stage: 4 = 2^4 amplitudes per thread (circuit_pass_fast_kernel, <= 256 VGPRs, two waves
+                     // per SIMD), 3 = 2^3 per thread (circuit_pass_r3_kernel: <= 128 VGPRs, four waves per SIMD, a third more stages)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
-  int max_threads = 512;
+  int max_threads = 1024;
   bool read_map = false;   // phase-0 CNOTs may target thread-held wires (general GF(2) read map, STAGE_CROSS_READ): fewer
                            // stages, but such a stage needs a barrier between its reads and its write-back, which costs more than
                            // the stages saved (MI355X, n = 16 / 20: +3.7 % / +2.8 %): off; kept for A/B (option "read_map")
@@ -192,14 +193,62 @@ enum FastStage : int { FS_FI01 = 0, FS_FI23, FS_RB = 2, FS_WB = 6, FS_KIND = 10,
 constexpr bool fast_stage_kind_supported(uint32_t kind) { return (kind & 7u) <= 4u && (kind >> 5) == 0u; }
 
 struct FastTables {
+  int r = 4;                        // register wires of the plan the tables were built for (slots per thread = 2^r)
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;   // word offset of each pass's header
   bool any_sign = false;            // some stage carries a CZ sign product (the SG tables exist)
   int max_tab_rows = 1;             // most (stages + sign stages) of any pass: table rows a workgroup keeps in LDS
 };
-// false (tables empty) when the plan is not eligible: tiles smaller than 2^10, a pass with more 16-byte matrix
-// pieces (16 per stage) than threads, or tables above `max_bytes`; the generic kernel then runs the plan.
+// false (tables empty) when the plan is not eligible: tiles smaller than 2^10 (2^9 with r = 3), a pass with more 16-byte
+// matrix pieces (4 r per stage) than threads, or tables above `max_bytes`; the generic kernel then runs the plan.
+// With r = 3 every table has 2^(n-3) words per stage, a thread has 8 slots and 3 basis offsets (same layout otherwise).
 bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out);
+
+// ---- compact tables (kernels_circuit8.hip: circuit_pass_r3_kernel) ---------------------------------
+// Every per-(tile row g, thread t) word of the fast tables is GF(2)-affine in (g, t): LDS slots, HBM byte offsets and
+// the slot-relative CZ sign bits are xor-sums of per-bit columns.  So  word(g, t) = LANE[row][t & 63] ^ UNI[g][row][t >> 6]:
+// 64 lane words per row (the same for every wave and tile row) and one wave-uniform word per (tile row, row, wave) --
+// a few KiB of LDS per workgroup instead of one word per thread and row (which at 8 amplitudes per thread and
+// 1024 threads would not fit beside a 2^13 tile).  The CZ sign common to a thread's slots is a QUADRATIC form of
+// (g, t): q(l + h) = q(l) + q(h) + B(l, h), l = lane part, h = wave and tile-row part; B(l, h) = parity(lane & M[g][w])
+// with a 6-bit mask M per (tile row, sign row, wave): word ^= 0xffff (pre) / 0xffff0000 (post) where that parity is odd.
+// Layout of `words` per pass, at pass_off[i]:
+//   header CH_WORDS words, then nstages stage headers of CS_WORDS words, then
+//   MAT[nstages * 12]: byte offset, in one circuit's gate array, of the 16-byte matrix piece thread p stages into LDS
+//   LANE[nrows][64], UNI[2^(n-k)][nrows][nwaves], MASK[2^(n-k)][nsign][nwaves] (pre mask | post mask << 8)
+// rows: 0 .. nstages-1: read slot | write slot << 16 of the stage;  then one row per stage carrying a sign (in stage
+// order): pre sign bits | post sign bits << 16;  then CR_IN_D, CR_IN_N, CR_OUT_D, CR_OUT_N, CR_SLOT.
+enum CompactHeader : int {
+  CH_NSTAGES = 0, CH_NROWS, CH_NSIGN, CH_SIGN_PRE, CH_SIGN_POST,
+  CH_DIRECT,        // bit 0: the first stage can take its amplitudes straight from HBM (row CR_IN_D), bit 1: the last stage can store straight to HBM
+  CH_ZINFO,         // support of |0..0>, as FH_ZINFO
+  CH_NWAVES, CH_MAT_OFF, CH_LANE_OFF, CH_UNI_OFF, CH_MASK_OFF,     // offsets from the pass's header
+  CH_IN_STEP_D = 12,    // [3] byte offsets xor-ed into a thread's CR_IN_D word for bit m of the element number (= slot number of the first stage)
+  CH_IN_STEP_N = 15,    // [3] the same for the ordinary tile fill (row CR_IN_N): 16 << phys-in position of enumeration bit k-3+m
+  CH_FILL_STEP = 18,    // [3] LDS slot masks of those enumeration bits (tile fill; thread part: low half of row CR_SLOT)
+  CH_DRAIN_STEP = 21,   // [3] LDS slot masks of the top 3 out-enumeration bits (tile drain; thread part: high half of row CR_SLOT)
+  CH_OUT_STEP_D = 24,   // [3] byte offsets of the slot-number bits of the last stage (row CR_OUT_D)
+  CH_OUT_STEP_N = 27,   // [3] byte offsets of the top 3 out-enumeration bits (row CR_OUT_N)
+  CH_WORDS = 32
+};
+enum CompactStage : int { CS_KIND = 0, CS_CROSS, CS_RB = 2, CS_WB = 5, CS_WORDS = 8 };
+enum CompactRow : int { CR_IN_D = 0, CR_IN_N, CR_OUT_D, CR_OUT_N, CR_SLOT, CR_EXTRA = 5 };   // + nstages + nsign
+constexpr int R3_MATS_BYTES = 3 * 64;   // LDS bytes of one stage's three 2x2 complex matrices
+struct CompactTables {
+  std::vector<uint32_t> words;
+  std::vector<uint32_t> pass_off;
+  int max_rows = 0, max_sign = 0, max_stages = 0;
+  // LDS of circuit_pass_r3_kernel: tile | matrices (two buffers) | matrix-piece offsets | LANE | UNI (one tile row) | MASK | prefetch words
+  size_t lds_bytes(int k) const {
+    const size_t nw = ((size_t)1 << (k - 3)) / 64;
+    return ((size_t)16 << k) + 2 * (size_t)max_stages * R3_MATS_BYTES + (size_t)max_stages * 12 * 4 + (size_t)max_rows * 64 * 4 +
+           (size_t)max_rows * nw * 4 + (size_t)(max_sign > 0 ? max_sign : 1) * nw * 4 + 2 * nw * 4 + 64;
+  }
+};
+// false (with msg) when the plan is not eligible (r != 3, tiles below 2^9, more matrix pieces than threads) or when a table
+// word turns out not to be affine in (g, t) -- every word is checked against its point evaluation (all (g, t) up to
+// 2^22 of them per row, a fixed sample beyond)
+bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg);
 
 // Returns false (with msg) on unsupported sizes.
 bool make_plan(int ansatz, int n, int layers, const PlanOptions& opt, Plan& out, std::string& msg);

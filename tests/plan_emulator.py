@@ -86,16 +86,17 @@ def popc(x):
     return c
 
 
-def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None, zslots=0):
+def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None, zslots=0, r=4):
     """One stage exactly as circuit_pass_fast_kernel runs it: slots and signs from the planner tables.
     direct_in = (buf, lo_in): the first stage takes its amplitudes straight from the pass's input buffer at the byte
     offsets of the FH_IN_TAB table (the tile, filled the ordinary way, must hold the same values);
     direct_out = (phys_of_slot, shift): the last stage's HBM offsets (FH_OUT_TAB) must be where the ordinary tile
     drain would put each slot."""
-    kt = k - 4
+    kt = k - r
     nthr = 1 << kt
+    nslots = 1 << r
     FS = FH + FH_WORDS + s * FS_WORDS
-    per_stage = 1 << (n - 4)
+    per_stage = 1 << (n - r)
     rw = F[int(F[FH + FH_RW_BASE]) + s * per_stage + (g << kt): int(F[FH + FH_RW_BASE]) + s * per_stage + (g << kt) + nthr].astype(np.int64)
     pre = (int(F[FH + FH_SIGN_PRE]) >> s) & 1
     post = (int(F[FH + FH_SIGN_POST]) >> s) & 1
@@ -104,36 +105,36 @@ def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None, z
     ng = kind & 7
     fi = [int(F[FS + FS_FI01]) & 0xFFFF, int(F[FS + FS_FI01]) >> 16, int(F[FS + FS_FI23]) & 0xFFFF, int(F[FS + FS_FI23]) >> 16]
     assert all(f != 0xFFFF for f in fi[:ng]) and all(f == 0xFFFF for f in fi[ng:])
-    rb = [int(F[FS + FS_RB + b]) for b in range(4)]
-    wb = [int(F[FS + FS_WB + b]) for b in range(4)]
+    rb = [int(F[FS + FS_RB + b]) for b in range(r)]
+    wb = [int(F[FS + FS_WB + b]) for b in range(r)]
 
     def addr(base_slot, basis, j):
         a = base_slot << 4
-        for b in range(4):
+        for b in range(r):
             if (j >> b) & 1:
                 a = a ^ basis[b]
         assert np.all(a % 16 == 0)
         return swz_inv(a >> 4)
-    rd = [addr(rw & 0xFFFF, rb, j) for j in range(16)]
-    wr = [addr(rw >> 16, wb, j) for j in range(16)]
+    rd = [addr(rw & 0xFFFF, rb, j) for j in range(nslots)]
+    wr = [addr(rw >> 16, wb, j) for j in range(nslots)]
     assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(1 << k))
     assert np.array_equal(np.sort(np.concatenate(wr)), np.arange(1 << k))
     # (the write-back stays in the thread's own group of 16 slots -- the slots differing in the register positions only;
     # the reads may come from anywhere in the tile: nothing has been written in this stage yet)
     own0 = np.stack(wr)
     regmask = 0
-    for b in range(4):
+    for b in range(r):
         regmask |= int(swz_inv(np.array([wb[b] >> 4]))[0])
     assert np.all((own0 & ~regmask) == (own0[0] & ~regmask)[None, :])
-    amp = [tile[rd[j]].copy() for j in range(16)]
+    amp = [tile[rd[j]].copy() for j in range(nslots)]
     if direct_in is not None:
         buf, lo_in = direct_in
         tab = int(F[FH + FH_IN_TAB])
         off0 = F[tab + (g << kt): tab + (g << kt) + nthr].astype(np.int64)
-        basis = [int(F[FH + FH_IN_BASIS + b]) for b in range(4)]
-        for j in range(16):
+        basis = [int(F[FH + FH_IN_BASIS + b]) for b in range(r)]
+        for j in range(nslots):
             off = off0.copy()
-            for b in range(4):
+            for b in range(r):
                 if (j >> b) & 1:
                     off ^= basis[b]
             assert np.all(off % 16 == 0)
@@ -151,29 +152,29 @@ def fast_stage(F, FH, s, g, k, n, tile, mats, direct_in=None, direct_out=None, z
     if pre or post:
         sgw = F[int(F[FH + FH_SG_BASE]) + s * per_stage + (g << kt): int(F[FH + FH_SG_BASE]) + s * per_stage + (g << kt) + nthr].astype(np.int64)
     if pre:
-        for j in range(16):
+        for j in range(nslots):
             amp[j] = np.where(((sgw >> j) & 1).astype(bool), -amp[j], amp[j])
     for a in range(ng):
         U = mats[fi[a]]
-        for j in range(16):
+        for j in range(nslots):
             if j & (1 << a):
                 continue
             j1 = j | (1 << a)
             x0, x1 = amp[j], amp[j1]
             amp[j], amp[j1] = U[0, 0] * x0 + U[0, 1] * x1, U[1, 0] * x0 + U[1, 1] * x1
     if post:
-        for j in range(16):
+        for j in range(nslots):
             amp[j] = np.where(((sgw >> (16 + j)) & 1).astype(bool), -amp[j], amp[j])
-    for j in range(16):
+    for j in range(nslots):
         tile[wr[j]] = amp[j]
     if direct_out is not None:
         phys_of_slot, sh = direct_out
         tab = int(F[FH + FH_OUT_TAB])
         off0 = F[tab + (g << kt): tab + (g << kt) + nthr].astype(np.int64)
-        basis = [int(F[FH + FH_OUT_BASIS + b]) for b in range(4)]
-        for j in range(16):
+        basis = [int(F[FH + FH_OUT_BASIS + b]) for b in range(r)]
+        for j in range(nslots):
             off = off0.copy()
-            for b in range(4):
+            for b in range(r):
                 if (j >> b) & 1:
                     off ^= basis[b]
             assert np.all(off % (1 << sh) == 0)
@@ -241,7 +242,7 @@ def run_plan(W, mats, state_in=None, fast=None):
                 use_out = int(Fw[FH + FH_OUT_TAB]) != 0 and nst > 1
                 zslots = int(Fw[FH + FH_ZINFO]) & 0xFFFF if (use_in and not (flags & PASS_INIT)) else 0
                 for si in range(nst):
-                    fast_stage(Fw, FH, si, g, k, n, tile, mats, zslots=zslots if si == 0 else 0,
+                    fast_stage(Fw, FH, si, g, k, n, tile, mats, zslots=zslots if si == 0 else 0, r=int(W[PH_R]),
                                direct_in=(buf, lo_in) if (si == 0 and use_in) else None,
                                direct_out=(phys_of_slot, 3 if (flags & PASS_FINAL) else 4) if (si == nst - 1 and use_out) else None)
             for si in range(nst if fast is None else 0):
@@ -364,3 +365,182 @@ def plan_stats(W):
         P = W[int(W[int(W[PH_OFF_PASSTAB]) + pi]):]
         stages.append(int(P[PW_NSTAGES]))
     return {"n": n, "k": k, "passes": np_, "stages": stages, "fused": int(W[PH_NFUSED]), "gates": int(W[PH_NGATES])}
+
+
+# ---- compact tables (plan.hpp: CompactTables; kernels_circuit8.hip: circuit_pass_r3_kernel) -----------------------
+CH_NSTAGES, CH_NROWS, CH_NSIGN, CH_SIGN_PRE, CH_SIGN_POST, CH_DIRECT, CH_ZINFO, CH_NWAVES, CH_MAT_OFF, CH_LANE_OFF, CH_UNI_OFF, CH_MASK_OFF = range(12)
+CH_IN_STEP_D, CH_IN_STEP_N, CH_FILL_STEP, CH_DRAIN_STEP, CH_OUT_STEP_D, CH_OUT_STEP_N, CH_WORDS = 12, 15, 18, 21, 24, 27, 32
+CS_KIND, CS_CROSS, CS_RB, CS_WB, CS_WORDS = 0, 1, 2, 5, 8
+CR_IN_D, CR_IN_N, CR_OUT_D, CR_OUT_N, CR_SLOT = range(5)
+
+
+def _comb3(j, basis):
+    return (basis[0] if j & 1 else 0) ^ (basis[1] if j & 2 else 0) ^ (basis[2] if j & 4 else 0)
+
+
+def run_plan_compact(W, compact, mats, state_in=None, direct=3, zero_support=True):
+    """The plan with 3 register wires run exactly as circuit_pass_r3_kernel runs it: every per-thread word is
+    LANE[row][lane] ^ UNI[tile row][row][wave] (sign rows: the bilinear lane x (wave, tile row) term through MASK), the tile is
+    filled / drained through rows CR_IN_N / CR_SLOT / CR_OUT_N or, where the tables allow, the first / last stage moves its
+    amplitudes straight between the buffers and the registers (rows CR_IN_D / CR_OUT_D)."""
+    W = np.asarray(W, dtype=np.uint32)
+    Cw, Coffs = compact
+    Cw = np.asarray(Cw, dtype=np.int64)
+    n, k, np_ = int(W[PH_N]), int(W[PH_K]), int(W[PH_NPASSES])
+    assert int(W[PH_R]) == 3
+    N, ksize, kt, gbits = 1 << n, 1 << k, k - 3, n - k
+    T = 1 << kt
+    t = np.arange(T, dtype=np.int64)
+    lane, wv = t & 63, t >> 6
+    buf = None if state_in is None else np.asarray(state_in, dtype=np.complex128).copy()
+    result = None
+    skipped = set()
+    for pi in range(np_):
+        P = W[int(W[int(W[PH_OFF_PASSTAB]) + pi]):]
+        flags = int(P[PW_FLAGS])
+        C = int(Coffs[pi])
+        H = [int(x) for x in Cw[C: C + CH_WORDS]]
+        nst, nrows, nsign, NW = H[CH_NSTAGES], H[CH_NROWS], H[CH_NSIGN], H[CH_NWAVES]
+        assert nst == int(P[PW_NSTAGES]) and NW == max(T // 64, 1) and int(P[PW_THREADS]) == T
+        sign_any = H[CH_SIGN_PRE] | H[CH_SIGN_POST]
+        init, fin = bool(flags & PASS_INIT), bool(flags & PASS_FINAL)
+        out_shift = 3 if fin else 4
+        direct_in = bool(H[CH_DIRECT] & 1) and not init and nst > 0 and bool(direct & 1)
+        direct_out = bool(H[CH_DIRECT] & 2) and nst > 1 and bool(direct & 2)
+        zs_ok = zero_support and direct == 3 and state_in is None
+        zinfo = H[CH_ZINFO] if zs_ok else 0
+        zgmask = zinfo if (init and gbits > 0) else 0
+        zslots = (zinfo & 0xFF) if (not init and direct_in) else 0
+        row0 = nst + nsign
+
+        def word(row, g):
+            lw = Cw[C + H[CH_LANE_OFF] + row * 64 + lane]
+            uw = Cw[C + H[CH_UNI_OFF] + (g * nrows + row) * NW + wv]
+            return lw ^ uw
+
+        def sign_word(sr, g):
+            w_ = word(nst + sr, g)
+            mk = Cw[C + H[CH_MASK_OFF] + (g * nsign + sr) * NW + wv]
+            ppre = (popc(lane & (mk & 0xFF)) & np.uint64(1)).astype(np.int64)
+            ppost = (popc(lane & (mk >> 8)) & np.uint64(1)).astype(np.int64)
+            return w_ ^ (ppre * 0xFFFF) ^ (ppost * 0xFFFF0000)
+
+        steps = {name: [H[base + m] for m in range(3)] for name, base in
+                 (("in_d", CH_IN_STEP_D), ("in_n", CH_IN_STEP_N), ("fill", CH_FILL_STEP), ("drain", CH_DRAIN_STEP),
+                  ("out_d", CH_OUT_STEP_D), ("out_n", CH_OUT_STEP_N))}
+        # the matrix pieces a workgroup stages: piece p of (stage, register bit) comes from fused gate (offset >> 6)
+        mat_of = {}
+        for p2 in range(nst * 12):
+            off = int(Cw[C + H[CH_MAT_OFF] + p2])
+            assert (off >> 4) & 3 == p2 & 3
+            mat_of[(p2 // 12, (p2 % 12) >> 2)] = off >> 6
+        out = np.zeros(N, dtype=np.complex128)
+        probs = np.zeros(N)
+        written = np.zeros(N, dtype=np.int64)
+        for g in range(1 << gbits):
+            zero_tile = init and gbits > 0 and g != 0
+            if zero_tile and (g & zgmask):
+                skipped.add((pi, g))
+                continue                          # nobody reads this tile: not written at all (stays poison below)
+            tile = np.zeros(ksize, dtype=np.complex128)          # indexed by SWIZZLED slot, as the kernel's LDS is
+            amp = None
+            if init:
+                if g == 0:
+                    tile[0] = 1.0
+            elif direct_in:
+                base = word(row0 + CR_IN_D, g)
+                amp = []
+                for j in range(8):
+                    off = base ^ _comb3(j, steps["in_d"])
+                    assert np.all(off % 16 == 0)
+                    if (zslots >> j) & 1:
+                        assert np.all((buf[off >> 4] == 0) | np.isnan(buf[off >> 4]))
+                        amp.append(np.zeros(T, dtype=np.complex128))
+                    else:
+                        assert not np.any(np.isnan(buf[off >> 4]))
+                        amp.append(buf[off >> 4].copy())
+            else:
+                base = word(row0 + CR_IN_N, g)
+                slot = word(row0 + CR_SLOT, g) & 0xFFFF
+                seen = np.zeros(ksize, dtype=np.int64)
+                for i in range(8):
+                    off = base ^ _comb3(i, steps["in_n"])
+                    sl = slot ^ _comb3(i, steps["fill"])
+                    tile[sl] = buf[off >> 4]
+                    seen[sl] += 1
+                assert np.all(seen == 1)
+            for s in range(0 if not zero_tile else nst, nst):
+                CS = C + CH_WORDS + s * CS_WORDS
+                kind = int(Cw[CS + CS_KIND])
+                ng, pre, post = kind & 7, (kind >> 3) & 1, (kind >> 4) & 1
+                assert ng <= 3 and int(Cw[CS + CS_CROSS]) == 0
+                rb = [int(Cw[CS + CS_RB + b]) for b in range(3)]
+                wb = [int(Cw[CS + CS_WB + b]) for b in range(3)]
+                rw = word(s, g)
+                if s == 0 and direct_in:
+                    a = amp
+                else:
+                    ra0 = (rw & 0xFFFF) << 4
+                    rd = [(ra0 ^ _comb3(j, rb)) >> 4 for j in range(8)]
+                    assert np.array_equal(np.sort(np.concatenate(rd)), np.arange(ksize))
+                    a = [tile[rd[j]].copy() for j in range(8)]
+                if pre or post:
+                    sg = sign_word(bin(sign_any & ((1 << s) - 1)).count("1"), g)
+                if pre:
+                    a = [np.where(((sg >> j) & 1).astype(bool), -a[j], a[j]) for j in range(8)]
+                for gi in range(ng):
+                    U = mats[mat_of[(s, gi)]]
+                    for j in range(8):
+                        if j & (1 << gi):
+                            continue
+                        j1 = j | (1 << gi)
+                        x0, x1 = a[j], a[j1]
+                        a[j], a[j1] = U[0, 0] * x0 + U[0, 1] * x1, U[1, 0] * x0 + U[1, 1] * x1
+                if post:
+                    a = [np.where(((sg >> (16 + j)) & 1).astype(bool), -a[j], a[j]) for j in range(8)]
+                if s == nst - 1 and direct_out:
+                    base = word(row0 + CR_OUT_D, g)
+                    for j in range(8):
+                        off = base ^ _comb3(j, steps["out_d"])
+                        assert np.all(off % (1 << out_shift) == 0)
+                        written[off >> out_shift] += 1
+                        if fin:
+                            probs[off >> out_shift] = np.abs(a[j]) ** 2
+                        else:
+                            out[off >> out_shift] = a[j]
+                else:
+                    wa0 = (rw >> 16) << 4
+                    wr = [(wa0 ^ _comb3(j, wb)) >> 4 for j in range(8)]
+                    assert np.array_equal(np.sort(np.concatenate(wr)), np.arange(ksize))
+                    for j in range(8):
+                        tile[wr[j]] = a[j]
+            if zero_tile or not direct_out:
+                if zero_tile:      # the kernel forms these addresses from the pass header (no table rows for g != 0)
+                    off0 = np.zeros(T, dtype=np.int64)
+                    for j in range(kt):
+                        off0 ^= ((t >> j) & 1) * int(P[PW_OUT_COL + j])
+                    for m in range(gbits):
+                        off0 ^= ((g >> m) & 1) * int(P[PW_OUT_GCOL + m])
+                    off0 = off0 << out_shift
+                else:
+                    off0 = word(row0 + CR_OUT_N, g)
+                slot = word(row0 + CR_SLOT, g) >> 16 if not zero_tile else np.zeros(T, dtype=np.int64)
+                for i in range(8):
+                    off = off0 ^ _comb3(i, steps["out_n"])
+                    x = tile[slot ^ _comb3(i, steps["drain"])] if not zero_tile else np.zeros(T, dtype=np.complex128)
+                    written[off >> out_shift] += 1
+                    if fin:
+                        probs[off >> out_shift] = np.abs(x) ** 2
+                    else:
+                        out[off >> out_shift] = x
+        if skipped and init:
+            assert np.all(written <= 1)
+            out[written == 0] = np.nan            # tiles the INIT pass leaves out: nobody may read what lies there
+        else:
+            assert np.all(written == 1)
+        buf = out
+        if fin:
+            result = probs
+        elif flags & PASS_FINAL_STATE:
+            result = out
+    return result

@@ -16,7 +16,11 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = os.path.join(REPO, "tensornetworks_amd", "csrc", "kernels_circuit.hip")
+CSRC = os.path.join(REPO, "tensornetworks_amd", "csrc")
+# (source file, mangled-name prefix of the kernels whose prefetch is hand-scheduled)
+TARGETS = [(os.path.join(CSRC, "kernels_circuit.hip"), "_ZN6bornvi24circuit_pass_fast_kernel"),
+           (os.path.join(CSRC, "kernels_circuit8.hip"), "_ZN6bornvi22circuit_pass_r3_kernel")]
+SRC = TARGETS[0][0]
 
 
 def regs_of(tok):
@@ -29,7 +33,7 @@ def regs_of(tok):
     return out
 
 
-def check(asm_text):
+def check(asm_text, prefix="_ZN6bornvi24circuit_pass_fast_kernel"):
     """Linear scan of each instantiation: a queue of outstanding vector-memory ops in issue order (hand-written
     ones inside ASMSTART/ASMEND and the compiler's own), drained by every s_waitcnt vmcnt(N) down to its N youngest.
     The scan follows the file order, i.e. the loop body once from the load site to the loop latch and on through the
@@ -38,7 +42,7 @@ def check(asm_text):
     "every stage kind is one of the twenty" -- and flags infeasible paths without them; the multi-trip parity test
     tests/test_gpu_circuit.py::test_persistent_tile_loop is the check on the hardware.)"""
     problems = []
-    kernels = re.split(r"\n(?=_ZN6bornvi24circuit_pass_fast_kernel[^\n]*:\s*;)", asm_text)
+    kernels = re.split(r"\n(?=" + re.escape(prefix) + r"[^\n]*:\s*;)", asm_text)
     n_sites = 0
     for chunk in kernels[1:]:
         name = chunk.split(":", 1)[0][-60:]
@@ -81,16 +85,23 @@ def check(asm_text):
 
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    rc = 0
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "kc.s")
-        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(REPO, "include"),
-                        "-I" + os.path.dirname(SRC), "-S", "--cuda-device-only", SRC, "-o", out], check=True,
-                       stderr=subprocess.DEVNULL)
-        n_sites, problems = check(open(out).read())
-    print(f"[check_async_regs] {n_sites} prefetch loads checked, {len(problems)} problem(s)")
-    for p in problems[:20]:
-        print("   ", p)
-    return 1 if problems or n_sites == 0 else 0
+        for src, prefix in TARGETS:
+            if not os.path.exists(src) or (only and only not in src):
+                continue
+            out = os.path.join(td, "kc.s")
+            subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(REPO, "include"),
+                            "-I" + os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out], check=True,
+                           stderr=subprocess.DEVNULL)
+            n_sites, problems = check(open(out).read(), prefix)
+            print(f"[check_async_regs] {os.path.basename(src)}: {n_sites} prefetch loads checked, {len(problems)} problem(s)")
+            for p in problems[:20]:
+                print("   ", p)
+            if problems or n_sites == 0:
+                rc = 1
+    return rc
 
 
 if __name__ == "__main__":
