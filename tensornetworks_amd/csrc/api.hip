@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -203,8 +204,11 @@ void free_plan(DevPlan* dp) {
 }
 
 // bytes one circuit needs in the workspace: its fused-gate matrices + two ping-pong states
+// slots of one circuit in the gate array: its fused matrices, then the scale of its probabilities (normalised gates)
+inline int gate_slots(const Plan& p) { return p.n_fused + 1; }
+
 size_t per_circuit_bytes(const Plan& p) {
-  size_t b = (size_t)p.n_fused * 64;
+  size_t b = (size_t)gate_slots(p) * 64;
   if (p.n_passes > 1) b += 2 * ((size_t)16 << p.n);
   return b ? b : 64;      // (a circuit without gates -- `basic` with 0 layers -- needs nothing; callers divide by this)
 }
@@ -339,7 +343,8 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   if (bc_max < 1) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small for one circuit");
   char* base = (char*)ws;
   double* gates = (double*)base;
-  const size_t gates_bytes = align_up((size_t)bc_max * p.n_fused * 64, 256);
+  const size_t gates_bytes = align_up((size_t)bc_max * gate_slots(p) * 64, 256);
+  const int normalise = dp->d_compact ? 1 : 0;
   const size_t state_bytes = align_up((size_t)bc_max * ((size_t)16 << n), 256);
   void* bufA = base + gates_bytes;
   void* bufB = base + gates_bytes + state_bytes;
@@ -357,14 +362,14 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
       const DevPlan::ShareTables* tabs = nullptr;
       rc = get_share_tables(h, dp, p_begin, (int)((batch - include_base) / 2), p_stride, include_base, cap, &tabs);
       if (rc) return rc;
-      const size_t gb = align_up((size_t)cap * p.n_fused * 64, 256);
+      const size_t gb = align_up((size_t)cap * gate_slots(p) * 64, 256);
       const size_t sb = align_up((size_t)cap * ((size_t)16 << n), 256);
       void* sA = base + gb;
       void* sB = base + gb + sb;
       double* trash = (double*)(base + gb + 2 * sb);
       for (const DevPlan::ShareChunk& ch : tabs->chunks) {
-        HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, 1, 0, 1, 0, 0, ch.bc, gates, ch.d_tab, st));
-        rc = run_passes(h, dp, ch.bc, nullptr, sA, sB, nullptr, probs, gates, (long long)p.n_fused * 8, st, &ch, trash);
+        HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, 1, 0, 1, 0, 0, ch.bc, gates, ch.d_tab, gate_slots(p), normalise, st));
+        rc = run_passes(h, dp, ch.bc, nullptr, sA, sB, nullptr, probs, gates, (long long)gate_slots(p) * 8, st, &ch, trash);
         if (rc) return rc;
       }
       return BORNVI_OK;
@@ -372,8 +377,8 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   }
   for (long long c0 = 0; c0 < batch; c0 += bc_max) {
     const int bc = (int)((batch - c0 < bc_max) ? batch - c0 : bc_max);
-    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, p_stride, include_base, c0, bc, gates, nullptr, st));
-    rc = run_passes(h, dp, bc, nullptr, bufA, bufB, nullptr, probs + (c0 << n), gates, (long long)p.n_fused * 8, st);
+    HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, thetas, p.n_params, shift_mode, p_begin, p_stride, include_base, c0, bc, gates, nullptr, gate_slots(p), normalise, st));
+    rc = run_passes(h, dp, bc, nullptr, bufA, bufB, nullptr, probs + (c0 << n), gates, (long long)gate_slots(p) * 8, st);
     if (rc) return rc;
   }
   return BORNVI_OK;
@@ -485,6 +490,9 @@ int bornvi_create(int device_ordinal, bornvi_handle* out) {
   bornvi_ctx* h = new (std::nothrow) bornvi_ctx();
   if (!h) { g_create_error = "out of host memory"; return BORNVI_ERR_INVALID; }
   h->device = device_ordinal;
+  // (A/B switches for whole test / bench runs; bornvi_set_option "reg_wires" / "read_map" are the per-handle form)
+  if (const char* e = std::getenv("BORNVI_REG_WIRES")) { if (e[0] == '3' || e[0] == '4') h->opt.r = e[0] - '0'; }
+  if (const char* e = std::getenv("BORNVI_READ_MAP")) h->opt.read_map = e[0] == '1';
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
     h->num_cus = prop.multiProcessorCount;
@@ -559,7 +567,7 @@ size_t bornvi_circuit_workspace_bytes(bornvi_handle h, int ansatz, int n, int la
   // (one circuit and one probability row more than `batch`: a parameter-shift batch with prefix sharing keeps the
   // base circuit in slot 0 even when the caller does not ask for its row, and a row for unwanted output)
   const size_t bb = (size_t)batch + (p.n_passes > 1 ? 1 : 0);
-  size_t b = 1024 + align_up(bb * p.n_fused * 64, 256);
+  size_t b = 1024 + align_up(bb * gate_slots(p) * 64, 256);
   if (p.n_passes > 1) b += 2 * align_up(bb * ((size_t)16 << n), 256) + align_up((size_t)8 << n, 256);
   return b;
 }
@@ -878,6 +886,8 @@ int bornvi_stein_matvec_kron(bornvi_handle h, int n, double length_scale, const 
   double* partials = (double*)(base + 256 + (np >= 3 ? 3 : (np == 2 ? 2 : 1)) * stb);
   DEVICE_SCOPE(h);
   HIPCHK(h, launch_kron_pack(n, length_scale, S, q, (double*)X, gate, st));
+  // (the 8-amplitude kernel reads pivot-normalised records; M = [[1, a], [a, 1]] has pivot 1: no scale to carry)
+  if (dp->d_compact) HIPCHK(h, launch_normalise_gates(gate, 1, st));
   // X -> (A -> B -> A ...) -> X : the last pass writes back into X (dead after pass 0; with a single
   // pass each workgroup owns a whole state and reads it completely before writing).
   rc = run_passes(h, dp, npk, X, A, Bf, X, nullptr, gate, 0, st);

@@ -32,6 +32,33 @@ __device__ __forceinline__ void gate_pair_inplace(double& x0r, double& x0i, doub
       : "v"(U[0]), "v"(U[1]), "v"(U[2]), "v"(U[3]), "v"(U[4]), "v"(U[5]), "v"(U[6]), "v"(U[7]));
 }
 
+// (In kernels_circuit.hip an experiment, BORNVI_U_SGPR; in kernels_circuit8.hip the production form: the matrices come by
+// scalar loads straight from the gate array.)
+// The same gate with the matrix in SCALAR registers (experiment BORNVI_U_SGPR, tools/probes): every instruction reads
+// exactly one matrix element, i.e. one SGPR pair -- inside the constant-bus limit of a VOP3 instruction.
+__device__ __forceinline__ void gate_pair_inplace_s(double& x0r, double& x0i, double& x1r, double& x1i,
+                                                    const double (&U)[8]) {
+  double t0, t1, t2, t3;
+  asm("v_mul_f64 %4, %9, %1\n\t"
+      "v_mul_f64 %5, %9, %0\n\t"
+      "v_mul_f64 %6, %13, %1\n\t"
+      "v_mul_f64 %7, %13, %0\n\t"
+      "v_fma_f64 %4, %10, %2, -%4\n\t"
+      "v_fma_f64 %5, %10, %3, %5\n\t"
+      "v_fma_f64 %6, %12, %0, -%6\n\t"
+      "v_fma_f64 %7, %12, %1, %7\n\t"
+      "v_fma_f64 %4, -%11, %3, %4\n\t"
+      "v_fma_f64 %5, %11, %2, %5\n\t"
+      "v_fma_f64 %6, -%15, %3, %6\n\t"
+      "v_fma_f64 %7, %15, %2, %7\n\t"
+      "v_fma_f64 %0, %8, %0, %4\n\t"
+      "v_fma_f64 %1, %8, %1, %5\n\t"
+      "v_fma_f64 %2, %14, %2, %6\n\t"
+      "v_fma_f64 %3, %14, %3, %7"
+      : "+v"(x0r), "+v"(x0i), "+v"(x1r), "+v"(x1i), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "s"(U[0]), "s"(U[1]), "s"(U[2]), "s"(U[3]), "s"(U[4]), "s"(U[5]), "s"(U[6]), "s"(U[7]));
+}
+
 __device__ __forceinline__ void load_u(const double2* __restrict__ Um, double (&U)[8]) {
   const double2 u00 = Um[0], u01 = Um[1], u10 = Um[2], u11 = Um[3];
   U[0] = u00.x; U[1] = u00.y; U[2] = u01.x; U[3] = u01.y; U[4] = u10.x; U[5] = u10.y; U[6] = u11.x; U[7] = u11.y;

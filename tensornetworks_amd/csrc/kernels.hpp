@@ -16,10 +16,13 @@ struct PrefixShare {
   const int* row_map = nullptr;          // final pass: output row of circuit b (< 0: goes to `trash`); null = row b
   double* trash = nullptr;               // 2^n doubles
 };
-// shift_tab (or null): per circuit of this launch, parameter * 2 + (1 for the minus shift), < 0 for the base circuit
+// shift_tab (or null): per circuit of this launch, parameter * 2 + (1 for the minus shift), < 0 for the base circuit.
+// gates: [batch][slots][8] doubles, slots >= nfused + 1.  normalise = 1 (circuit_pass_r3_kernel): pivot-normalised records
+// (kernels_circuit.hip: build_gates_kernel) and, in slot nfused, the scale of the circuit's probabilities.
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
                               int shift_mode, int p_begin, int p_stride, int include_base, long long b_offset, int batch,
-                              double* gates, const int* shift_tab, hipStream_t st);
+                              double* gates, const int* shift_tab, int slots, int normalise, hipStream_t st);
+hipError_t launch_normalise_gates(double* gates, int count, hipStream_t st);   // raw [count][8] -> records, in place
 hipError_t prepare_circuit_kernel(size_t lds_bytes);
 hipError_t read_circuit_stamps(unsigned long long* out16);   // diagnostic builds (BORNVI_STAMPS) only: zeros otherwise
 hipError_t launch_circuit_pass(const uint32_t* plan, uint32_t pass_off, int n, int k, int threads, size_t lds, int batch,

@@ -40,7 +40,7 @@ __device__ inline void elem_matrix(uint32_t kind, double t, double (&m)[8]) {
 __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const double* __restrict__ thetas,
                                    long long theta_stride, int shift_mode, int p_begin, int p_stride, int include_base,
                                    long long b_offset, int batch, double* __restrict__ gates,
-                                   const int* __restrict__ shift_tab) {
+                                   const int* __restrict__ shift_tab, int slots, int normalise) {
   const uint32_t nf = plan[PH_NFUSED];
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)batch * nf) return;
@@ -84,9 +84,59 @@ __global__ void build_gates_kernel(const uint32_t* __restrict__ plan, const doub
 #pragma unroll
     for (int i = 0; i < 8; ++i) U[i] = R[i];
   }
-  double* dst = gates + (b * nf + f) * 8;
+  double* dst = gates + (b * slots + f) * 8;
+  if (normalise) {
+    // Record of circuit_pass_r3_kernel: the matrix divided by a pivot p so that one row reads (1, B) -- 12 instead of 16
+    // fp64 instructions per amplitude pair:  z0 = x0 + B x1,  z1 = C x0 + D x1.  p = u00 (z = (y0, y1) / p) or, where
+    // |u10| > |u00|, p = u10 with the two outputs exchanged (z = (y1, y0) / p: the kernel folds the exchange into the
+    // address the pair is written to).  |p|^2 >= 1/2 for a unitary column; the product of all |p|^2 of a circuit scales
+    // its probabilities back (gate_scale_kernel); a global phase does not show in |psi|^2.
+    const double m0 = U[0] * U[0] + U[1] * U[1], m1 = U[4] * U[4] + U[5] * U[5];
+    const bool sw = m1 > m0;
+    const double pr = sw ? U[4] : U[0], pi = sw ? U[5] : U[1], pm = sw ? m1 : m0;
+    const double ir = pr / pm, ii = -pi / pm;                      // 1 / p
+    const double* r0 = sw ? U + 4 : U;        // the row that becomes (1, B)
+    const double* r1 = sw ? U : U + 4;        // the row that becomes (C, D)
+    dst[0] = r0[2] * ir - r0[3] * ii; dst[1] = r0[2] * ii + r0[3] * ir;
+    dst[2] = r1[0] * ir - r1[1] * ii; dst[3] = r1[0] * ii + r1[1] * ir;
+    dst[4] = r1[2] * ir - r1[3] * ii; dst[5] = r1[2] * ii + r1[3] * ir;
+    dst[6] = pm;
+    dst[7] = sw ? 1.0 : 0.0;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) dst[i] = U[i];
+}
+
+// scale of circuit b's probabilities under the normalised gates: product of the pivots' |p|^2 in gate order (fixed order:
+// deterministic), kept in slot nf of the circuit's gate array
+__global__ __launch_bounds__(64) void gate_scale_kernel(double* __restrict__ gates, int nf, int slots, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double* g = gates + (long long)b * slots * 8;
+  double sc = 1.0;
+  for (int f = 0; f < nf; ++f) sc *= g[f * 8 + 6];
+  g[(long long)nf * 8] = sc;
+}
+
+// raw 2x2 matrices [count][8] -> normalised records in place (the matrix-free Stein mat-vec writes its one shared matrix raw)
+__global__ void normalise_gates_kernel(double* __restrict__ gates, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double* dst = gates + (long long)i * 8;
+  double U[8];
+  for (int e = 0; e < 8; ++e) U[e] = dst[e];
+  const double m0 = U[0] * U[0] + U[1] * U[1], m1 = U[4] * U[4] + U[5] * U[5];
+  const bool sw = m1 > m0;
+  const double pr = sw ? U[4] : U[0], pi = sw ? U[5] : U[1], pm = sw ? m1 : m0;
+  const double ir = pr / pm, ii = -pi / pm;
+  const double* r0 = sw ? U + 4 : U;
+  const double* r1 = sw ? U : U + 4;
+  dst[0] = r0[2] * ir - r0[3] * ii; dst[1] = r0[2] * ii + r0[3] * ir;
+  dst[2] = r1[0] * ir - r1[1] * ii; dst[3] = r1[0] * ii + r1[1] * ir;
+  dst[4] = r1[2] * ir - r1[3] * ii; dst[5] = r1[2] * ii + r1[3] * ir;
+  dst[6] = pm;
+  dst[7] = sw ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,31 +466,6 @@ __global__ __launch_bounds__(512) void circuit_pass_kernel(
 //     final FMAs that each overwrite the operand they read last): the compiler's version needed 32 register
 //     moves per gate to merge the conditional gate back into the amplitude registers.
 // ------------------------------------------------------------------------------------------------
-// The same gate with the matrix in SCALAR registers (experiment BORNVI_U_SGPR, tools/probes): every instruction reads
-// exactly one matrix element, i.e. one SGPR pair -- inside the constant-bus limit of a VOP3 instruction.
-__device__ __forceinline__ void gate_pair_inplace_s(double& x0r, double& x0i, double& x1r, double& x1i,
-                                                    const double (&U)[8]) {
-  double t0, t1, t2, t3;
-  asm("v_mul_f64 %4, %9, %1\n\t"
-      "v_mul_f64 %5, %9, %0\n\t"
-      "v_mul_f64 %6, %13, %1\n\t"
-      "v_mul_f64 %7, %13, %0\n\t"
-      "v_fma_f64 %4, %10, %2, -%4\n\t"
-      "v_fma_f64 %5, %10, %3, %5\n\t"
-      "v_fma_f64 %6, %12, %0, -%6\n\t"
-      "v_fma_f64 %7, %12, %1, %7\n\t"
-      "v_fma_f64 %4, -%11, %3, %4\n\t"
-      "v_fma_f64 %5, %11, %2, %5\n\t"
-      "v_fma_f64 %6, -%15, %3, %6\n\t"
-      "v_fma_f64 %7, %15, %2, %7\n\t"
-      "v_fma_f64 %0, %8, %0, %4\n\t"
-      "v_fma_f64 %1, %8, %1, %5\n\t"
-      "v_fma_f64 %2, %14, %2, %6\n\t"
-      "v_fma_f64 %3, %14, %3, %7"
-      : "+v"(x0r), "+v"(x0i), "+v"(x1r), "+v"(x1i), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "s"(U[0]), "s"(U[1]), "s"(U[2]), "s"(U[3]), "s"(U[4]), "s"(U[5]), "s"(U[6]), "s"(U[7]));
-}
-
 __device__ __forceinline__ double uniform_to_sgpr(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
@@ -1274,12 +1299,19 @@ hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g3
 // ---- launchers (called from api.hip) --------------------------------------------------------------------
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
                               int shift_mode, int p_begin, int p_stride, int include_base, long long b_offset, int batch,
-                              double* gates, const int* shift_tab, hipStream_t st) {
+                              double* gates, const int* shift_tab, int slots, int normalise, hipStream_t st) {
   const long long total = (long long)batch * nfused;
   if (total == 0) return hipSuccess;
   const int bs = 128;
   build_gates_kernel<<<dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st>>>(
-      plan, thetas, theta_stride, shift_mode, p_begin, p_stride, include_base, b_offset, batch, gates, shift_tab);
+      plan, thetas, theta_stride, shift_mode, p_begin, p_stride, include_base, b_offset, batch, gates, shift_tab, slots, normalise);
+  if (normalise) gate_scale_kernel<<<dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st>>>(gates, nfused, slots, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_normalise_gates(double* gates, int count, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  normalise_gates_kernel<<<dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st>>>(gates, count);
   return hipGetLastError();
 }
 

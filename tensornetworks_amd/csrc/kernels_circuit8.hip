@@ -7,6 +7,9 @@
 // per-thread table row would be 4 KiB per stage and no longer fit beside the tile, so the tables come in their
 // COMPACT form (plan.hpp: CompactTables): every per-(tile row, thread) word is GF(2)-affine in (tile row, thread), i.e.
 // word = LANE[row][lane] ^ UNI[row][wave], 64 + 16 words per row in LDS.
+// The fused 2x2 matrices are wave-uniform: they come by SCALAR loads straight from the gate array into SGPRs (every
+// instruction of the gate reads one matrix element = one SGPR pair, the constant-bus limit of VOP3) -- no LDS staging, no
+// broadcast ds_read (which was a third of the LDS traffic of a stage), 16 VGPRs less.
 #include <hip/hip_runtime.h>
 
 #include "circuit_dev.hpp"
@@ -15,10 +18,66 @@
 
 namespace bornvi {
 
+// timing-only ablations (wrong results by construction; tools/probes/build_r3_variants.sh): what the parts of a stage cost
+#ifndef BORNVI_R3_NO_MATLOAD
+#define BORNVI_R3_NO_MATLOAD 0     // 1: the gates' matrices are not read from LDS
+#endif
+#ifndef BORNVI_R3_NO_STAGES
+#define BORNVI_R3_NO_STAGES 0      // 1: tile in, tile out, nothing in between (the HBM side of a pass alone)
+#endif
+#ifndef BORNVI_R3_STAGGER
+#define BORNVI_R3_STAGGER 0        // experiment: workgroups start 0 .. 3 quarters of this many 64-cycle ticks late (phase spread over the CUs)
+#endif
+#ifndef BORNVI_R3_MAT_UPFRONT
+#define BORNVI_R3_MAT_UPFRONT 1    // 1: the stage's matrices are requested together, ahead of the amplitude reads; 0: each one in front of its gate (A/B)
+#endif
+#ifndef BORNVI_R3_NO_GATES
+#define BORNVI_R3_NO_GATES 0       // 1: the stages' LDS round trips and signs without the gate arithmetic
+#endif
+
 namespace {
+
+// One gate on an amplitude pair, matrix as the pivot-normalised RECORD build_gates_kernel writes (kernels_circuit.hip):
+// R = (B, C, D, |p|^2, exchange flag):  z0 = x0 + B x1,  z1 = C x0 + D x1  -- 12 fp64 instructions instead of the 16 of a
+// general complex 2x2 (the pivot's modulus is carried as a scale of the circuit's probabilities, its phase is global).
+// In place; every instruction reads one record element = one SGPR pair (the constant-bus limit of VOP3).
+__device__ __forceinline__ void gate_pair8(double& x0r, double& x0i, double& x1r, double& x1i, const double (&R)[8]) {
+  double t2, t3;
+  asm("v_mul_f64 %4, %9, %1\n\t"          // t2 = Ci x0i
+      "v_mul_f64 %5, %9, %0\n\t"          // t3 = Ci x0r
+      "v_fma_f64 %4, %8, %0, -%4\n\t"     // t2 = Cr x0r - Ci x0i
+      "v_fma_f64 %5, %8, %1, %5\n\t"      // t3 = Cr x0i + Ci x0r
+      "v_fma_f64 %0, %6, %2, %0\n\t"      // x0r += Br x1r
+      "v_fma_f64 %1, %6, %3, %1\n\t"      // x0i += Br x1i
+      "v_fma_f64 %0, -%7, %3, %0\n\t"     // x0r -= Bi x1i
+      "v_fma_f64 %1, %7, %2, %1\n\t"      // x0i += Bi x1r
+      "v_fma_f64 %4, -%11, %3, %4\n\t"    // t2 -= Di x1i
+      "v_fma_f64 %5, %11, %2, %5\n\t"     // t3 += Di x1r
+      "v_fma_f64 %2, %10, %2, %4\n\t"     // x1r = Dr x1r + t2
+      "v_fma_f64 %3, %10, %3, %5"          // x1i = Dr x1i + t3
+      : "+v"(x0r), "+v"(x0i), "+v"(x1r), "+v"(x1i), "=&v"(t2), "=&v"(t3)
+      : "s"(R[0]), "s"(R[1]), "s"(R[2]), "s"(R[3]), "s"(R[4]), "s"(R[5]));
+}
+// the record's exchange flag (1.0 / 0.0): the two results of every pair of this gate change places
+__device__ __forceinline__ bool rec_swap(const double (&R)[8]) { return __double2hiint(R[7]) != 0; }
+
+// the 2x2 complex matrix at a wave-uniform address: one 64-byte scalar load
+__device__ __forceinline__ void load_u8(const double* __restrict__ Um, double (&U)[8]) {
+#if BORNVI_R3_NO_MATLOAD
+  (void)Um;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) asm volatile("" : "=s"(U[e]));
+#else
+#pragma unroll
+  for (int e = 0; e < 8; ++e) U[e] = Um[e];
+#endif
+}
 
 __device__ __forceinline__ uint32_t comb3(int j, const uint32_t (&B)[3]) {
   return ((j & 1) ? B[0] : 0u) ^ ((j & 2) ? B[1] : 0u) ^ ((j & 4) ? B[2] : 0u);
+}
+__device__ __forceinline__ uint32_t comb3_rt(uint32_t j, const uint32_t (&B)[3]) {     // (wave-uniform j: scalar selects)
+  return ((j & 1u) ? B[0] : 0u) ^ ((j & 2u) ? B[1] : 0u) ^ ((j & 4u) ? B[2] : 0u);
 }
 
 // xor over bits j in [0, nbits) of v of cols[j] (GF(2)-linear phys-out address, plan.hpp: PW_OUT_COL)
@@ -35,7 +94,7 @@ __device__ __forceinline__ void gate8(double (&ar)[8], double (&ai)[8], const do
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j & (1 << I)) continue;
-    gate_pair_inplace(ar[j], ai[j], ar[j | (1 << I)], ai[j | (1 << I)], U);
+    gate_pair8(ar[j], ai[j], ar[j | (1 << I)], ai[j | (1 << I)], U);
   }
 }
 
@@ -52,10 +111,10 @@ __device__ __forceinline__ void sign8(uint32_t m, double (&ar)[8], double (&ai)[
 // the results of slot jj leave the thread: to LDS (IO 0 / 1), or straight to HBM (IO 2: 16 bytes, or |amp|^2 as 8 bytes)
 template <int IO, bool FIN>
 __device__ __forceinline__ void put_slot(double xr, double xi, int jj, char* __restrict__ lds, uint32_t wa0, const uint32_t (&WB)[3],
-                                         const uint32_t (&hb)[3], void* hbm_base) {
+                                         const uint32_t (&hb)[3], void* hbm_base, double scale) {
   if (IO == 2) {
     const uint32_t ha = wa0 ^ comb3(jj, hb);
-    if (FIN) async_store8(ha, xr * xr + xi * xi, hbm_base);
+    if (FIN) async_store8(ha, (xr * xr + xi * xi) * scale, hbm_base);
     else async_store16(ha, (d2_t){xr, xi}, hbm_base);
   } else {
     *reinterpret_cast<double2*>(lds + (wa0 ^ comb3(jj, WB))) = make_double2(xr, xi);
@@ -67,18 +126,18 @@ __device__ __forceinline__ void put_slot(double xr, double xi, int jj, char* __r
 template <int I, bool POST, int IO, bool FIN>
 __device__ __forceinline__ void gate8_last(double (&ar)[8], double (&ai)[8], const double (&U)[8], uint32_t post_bits,
                                            char* __restrict__ lds, uint32_t wa0, const uint32_t (&WB)[3], const uint32_t (&hb)[3],
-                                           void* hbm_base) {
+                                           void* hbm_base, double scale) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j & (1 << I)) continue;
     const int j1 = j | (1 << I);
-    gate_pair_inplace(ar[j], ai[j], ar[j1], ai[j1], U);
+    gate_pair8(ar[j], ai[j], ar[j1], ai[j1], U);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int jj = q ? j1 : j;
       double xr = ar[jj], xi = ai[jj];
       if (POST) { xr = flip_sign(xr, post_bits, jj); xi = flip_sign(xi, post_bits, jj); }
-      put_slot<IO, FIN>(xr, xi, jj, lds, wa0, WB, hb, hbm_base);
+      put_slot<IO, FIN>(xr, xi, jj, lds, wa0, WB, hb, hbm_base, scale);
     }
   }
 }
@@ -87,10 +146,18 @@ __device__ __forceinline__ void gate8_last(double (&ar)[8], double (&ai)[8], con
 // IO: 0 = LDS -> LDS; 1 = the amplitudes are the prefetched registers `v` (first stage of a pass, results to LDS);
 // 2 = LDS -> HBM (last stage of a pass).
 template <int NG, bool PRE, bool POST, int IO, bool FIN>
-__device__ __forceinline__ void stage8(char* __restrict__ lds, const double2* __restrict__ Us, uint32_t my_rw, uint32_t my_sg,
-                                       const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8], uint32_t hbm_off,
-                                       const uint32_t (&hb)[3], void* hbm_base, bool cross) {
+__device__ __forceinline__ void stage8(char* __restrict__ lds, const char* __restrict__ gb, const uint32_t (&MAT)[3], uint32_t my_rw,
+                                       uint32_t my_sg, const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8], uint32_t hbm_off,
+                                       const uint32_t (&hb)[3], void* hbm_base, bool cross, double scale) {
   double ar[8], ai[8];
+  // all matrices of the stage are requested before the amplitudes (scalar loads return out of order with LDS reads: one
+  // lgkmcnt(0) in front of the first gate covers both)
+  // (two register sets: the third matrix is requested into the first set behind gate 0 and arrives under gate 1's FMAs)
+  double Ua[8], Ub[8];
+#if BORNVI_R3_MAT_UPFRONT
+  if (NG > 0) load_u8(reinterpret_cast<const double*>(gb + MAT[0]), Ua);
+  if (NG > 1) load_u8(reinterpret_cast<const double*>(gb + MAT[1]), Ub);
+#endif
   if (IO == 1) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ar[j] = v[j].x; ai[j] = v[j].y; }
@@ -108,31 +175,53 @@ __device__ __forceinline__ void stage8(char* __restrict__ lds, const double2* __
   }
   if (PRE) sign8(my_sg & 0xffu, ar, ai);
   uint32_t wa0 = (IO == 2) ? hbm_off : (my_rw >> 16) << 4;
-  double U[8];
-  if (NG > 1) { load_u(Us, U); gate8<0>(ar, ai, U); }
-  if (NG > 2) { load_u(Us + 4, U); gate8<1>(ar, ai, U); }
+#if !BORNVI_R3_MAT_UPFRONT
+  if (NG > 0) load_u8(reinterpret_cast<const double*>(gb + MAT[0]), Ua);
+#endif
+  // sig: bit i set = the results of register bit i's gate change places (the record's pivot sits in the other row): slot j
+  // of the registers then holds the amplitude of slot j ^ sig -- folded into the write address and the post sign bits
+  uint32_t sig = 0;
+  if (NG > 1) {
+    gate8<0>(ar, ai, Ua);
+    sig |= rec_swap(Ua) ? 1u : 0u;
+#if !BORNVI_R3_MAT_UPFRONT
+    load_u8(reinterpret_cast<const double*>(gb + MAT[1]), Ub);
+#endif
+    if (NG > 2) load_u8(reinterpret_cast<const double*>(gb + MAT[2]), Ua);
+  }
+  if (NG > 2) { gate8<1>(ar, ai, Ub); sig |= rec_swap(Ub) ? 2u : 0u; }
+  if (NG > 0) sig |= rec_swap(NG == 2 ? Ub : Ua) ? (1u << (NG - 1)) : 0u;
+  uint32_t post_bits = my_sg >> 16;
+  if (POST && NG > 0) {
+    if (sig & 1u) post_bits = ((post_bits & 0x55u) << 1) | ((post_bits >> 1) & 0x55u);
+    if (sig & 2u) post_bits = ((post_bits & 0x33u) << 2) | ((post_bits >> 2) & 0x33u);
+    if (sig & 4u) post_bits = ((post_bits & 0x0fu) << 4) | ((post_bits >> 4) & 0x0fu);
+  }
+  if (NG > 0) wa0 ^= (IO == 2) ? comb3_rt(sig, hb) : comb3_rt(sig, WB);
   if (NG > 0) {
-    load_u(Us + 4 * (NG - 1), U);
     asm volatile("" : "+v"(wa0));     // the write base is formed here, before the last gate
-    gate8_last<(NG > 0 ? NG - 1 : 0), POST, IO, FIN>(ar, ai, U, my_sg >> 16, lds, wa0, WB, hb, hbm_base);
+    gate8_last<(NG > 0 ? NG - 1 : 0), POST, IO, FIN>(ar, ai, NG == 2 ? Ub : Ua, post_bits, lds, wa0, WB, hb, hbm_base, scale);
   } else {
     asm volatile("" : "+v"(wa0));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       double xr = ar[j], xi = ai[j];
-      if (POST) { xr = flip_sign(xr, my_sg >> 16, j); xi = flip_sign(xi, my_sg >> 16, j); }
-      put_slot<IO, FIN>(xr, xi, j, lds, wa0, WB, hb, hbm_base);
+      if (POST) { xr = flip_sign(xr, post_bits, j); xi = flip_sign(xi, post_bits, j); }
+      put_slot<IO, FIN>(xr, xi, j, lds, wa0, WB, hb, hbm_base, scale);
     }
   }
 }
 
 template <int IO, bool FIN>
-__device__ __forceinline__ void dispatch8(uint32_t kind, char* __restrict__ lds, const double2* __restrict__ Us, uint32_t my_rw,
-                                          uint32_t my_sg, const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8],
-                                          uint32_t hbm_off, const uint32_t (&hb)[3], void* hbm_base, bool cross) {
+__device__ __forceinline__ void dispatch8(uint32_t kind, char* __restrict__ lds, const char* __restrict__ gb, const uint32_t (&MAT)[3],
+                                          uint32_t my_rw, uint32_t my_sg, const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8],
+                                          uint32_t hbm_off, const uint32_t (&hb)[3], void* hbm_base, bool cross, double scale) {
 #define BORNVI_ST8(NG, PRE, POST) \
-  case (NG) | ((PRE) << 3) | ((POST) << 4): stage8<NG, PRE, POST, IO, FIN>(lds, Us, my_rw, my_sg, RB, WB, v, hbm_off, hb, hbm_base, cross); break;
+  case (NG) | ((PRE) << 3) | ((POST) << 4): stage8<NG, PRE, POST, IO, FIN>(lds, gb, MAT, my_rw, my_sg, RB, WB, v, hbm_off, hb, hbm_base, cross, scale); break;
 #define BORNVI_ST8_NG(PRE, POST) BORNVI_ST8(0, PRE, POST) BORNVI_ST8(1, PRE, POST) BORNVI_ST8(2, PRE, POST) BORNVI_ST8(3, PRE, POST)
+#if BORNVI_R3_NO_GATES
+  kind &= ~7u;
+#endif
   switch (kind) {
     BORNVI_ST8_NG(0, 0)
     BORNVI_ST8_NG(1, 0)
@@ -164,18 +253,14 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
   const int kt = k - 3;
   const uint32_t ksize = 1u << k;
   const int gbits = n - k;
-  const int nstages = (int)H[CH_NSTAGES];
+  const int nstages = BORNVI_R3_NO_STAGES ? 0 : (int)H[CH_NSTAGES];
   const uint32_t nrows = H[CH_NROWS], nsign = H[CH_NSIGN], NW = H[CH_NWAVES];
   const uint32_t sign_any = H[CH_SIGN_PRE] | H[CH_SIGN_POST];
   const bool init = flags & PASS_INIT, fin = flags & PASS_FINAL;
   const int out_shift = fin ? 3 : 4;
-  // ---- LDS: tile | matrices (two buffers) | matrix-piece offsets | LANE rows | UNI rows of one tile row | MASK ----
+  // ---- LDS: tile | LANE rows | UNI rows of one tile row | MASK ----
   char* __restrict__ lds = reinterpret_cast<char*>(tile);
-  const uint32_t npieces = (uint32_t)nstages * 12u;
-  double2* __restrict__ mats_a = tile + ksize;
-  double2* __restrict__ mats_b = mats_a + npieces;
-  uint32_t* __restrict__ mat_tab = reinterpret_cast<uint32_t*>(mats_b + npieces);
-  uint32_t* __restrict__ lane_tab = mat_tab + npieces;
+  uint32_t* __restrict__ lane_tab = reinterpret_cast<uint32_t*>(tile + ksize);
   uint32_t* __restrict__ uni_tab = lane_tab + nrows * 64u;
   uint32_t* __restrict__ mask_tab = uni_tab + nrows * NW;
   // (direct_mask: bit 0 / 1 allow the direct first / last stage; bit 2: walk the tiles backwards; bit 3: support of |0..0>)
@@ -187,24 +272,23 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
   const uint32_t drain_step[3] = {H[CH_DRAIN_STEP], H[CH_DRAIN_STEP + 1], H[CH_DRAIN_STEP + 2]};
   const uint32_t out_step_d[3] = {H[CH_OUT_STEP_D], H[CH_OUT_STEP_D + 1], H[CH_OUT_STEP_D + 2]};
   const uint32_t out_step_n[3] = {H[CH_OUT_STEP_N], H[CH_OUT_STEP_N + 1], H[CH_OUT_STEP_N + 2]};
-  const uint32_t row0 = (uint32_t)nstages + nsign;
+  const uint32_t row0 = H[CH_NSTAGES] + nsign;
   const uint32_t row_in = row0 + (direct_in ? CR_IN_D : CR_IN_N);
   const uint32_t row_out_d = row0 + CR_OUT_D, row_out_n = row0 + CR_OUT_N, row_slot = row0 + CR_SLOT;
   const uint32_t* __restrict__ UNI = C + H[CH_UNI_OFF];
   const uint32_t* __restrict__ MASK = C + H[CH_MASK_OFF];
   // tile-row independent tables -> LDS (trip -1 already reads them for the first prefetch)
   for (uint32_t i = t; i < nrows * 64u; i += T) lane_tab[i] = C[H[CH_LANE_OFF] + i];
-  for (uint32_t i = t; i < npieces; i += T) mat_tab[i] = C[H[CH_MAT_OFF] + i];
   __syncthreads();
 
+#if BORNVI_R3_STAGGER
+  for (uint32_t q = 0; q < ((blockIdx.x >> 3) & 3u) * (BORNVI_R3_STAGGER / 4); ++q) __builtin_amdgcn_s_sleep(1);
+#endif
   d2_t v[8];                // amplitudes of the NEXT tile (in flight during the current tile's stages)
-  d2_t mp;                  // its piece of the matrices
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (d2_t){0.0, 0.0};
-  mp = (d2_t){0.0, 0.0};
   uint32_t g_pref = 0xffffffffu, in_uni = 0;   // tile row whose CR_IN uniform word is in in_uni
   uint32_t g_tab = 0xffffffffu;                // tile row whose UNI / MASK rows are in LDS
-  uint32_t parity = 1;
   const uint32_t* __restrict__ CS0 = C + CH_WORDS;
 
 #define BORNVI_RUN_STAGE8(S_, IO_)                                                                              \
@@ -213,6 +297,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     const uint32_t kind_ = CS_[CS_KIND];                                                                        \
     const uint32_t RB_[3] = {CS_[CS_RB], CS_[CS_RB + 1], CS_[CS_RB + 2]};                                       \
     const uint32_t WB_[3] = {CS_[CS_WB], CS_[CS_WB + 1], CS_[CS_WB + 2]};                                       \
+    const uint32_t MAT_[3] = {CS_[CS_MAT], CS_[CS_MAT + 1], CS_[CS_MAT + 2]};                                   \
     const uint32_t rw_ = lane_tab[(uint32_t)(S_) * 64u + lane] ^ uni_tab[(uint32_t)(S_) * NW + wv];             \
     uint32_t sg_ = 0;                                                                                           \
     if (kind_ >> 3) {                                                                                           \
@@ -224,9 +309,9 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     }                                                                                                           \
     const uint32_t ho_ = (IO_) == 2 ? (lane_tab[row_out_d * 64u + lane] ^ uni_tab[row_out_d * NW + wv]) : 0u;   \
     if ((IO_) == 2 && fin)                                                                                      \
-      dispatch8<IO_, true>(kind_, lds, mats + (S_) * 12, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u); \
+      dispatch8<IO_, true>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, scale); \
     else                                                                                                        \
-      dispatch8<IO_, false>(kind_, lds, mats + (S_) * 12, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u); \
+      dispatch8<IO_, false>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, 1.0); \
   } while (0)
 
   const long long walk_flip = total_tiles - 1;
@@ -236,7 +321,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
   const uint32_t zgmask = zskip ? zinfo : 0u;
   const uint32_t zslots = (!init && direct_in) ? (zinfo & 0xffu) : 0u;
   const uint32_t zs_nb = (uint32_t)(total_tiles >> gbits), zs_gm1 = (1u << gbits) - 1u;
-  for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x, parity ^= 1u) {
+  for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x) {
     const bool real = Scur >= 0;
     const long long Snext = Scur + gridDim.x;
     const bool has_next = Snext < total_tiles;
@@ -255,9 +340,9 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     const long long b = real ? (Tcur >> gbits) : 0;
     const bool zero_tile = zskip && real && g != 0u;
     const bool noop_tile = zero_tile && (g & zgmask) != 0u;
-    const bool next_zero = zskip && has_next && (Tnext & ((1ll << gbits) - 1)) != 0;
-    double2* __restrict__ mats = parity ? mats_b : mats_a;
-    double2* __restrict__ mats_next = parity ? mats_a : mats_b;
+    const char* __restrict__ gb = reinterpret_cast<const char*>(gates + b * gate_stride);   // this circuit's fused matrices
+    // (normalised gates: the pivots' |p|^2 multiply back into the probabilities; slot nfused of the circuit's gate array)
+    const double scale = (fin && real) ? *reinterpret_cast<const double*>(gb + (size_t)plan[PH_NFUSED] * 64u) : 1.0;
     double2* dst = out + b * state_stride;
     double* pdst = probs + (b << n);
     if (fin && share.row_map) {
@@ -291,7 +376,6 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
         g_pref = gn_;
         in_uni = UNI[((size_t)gn_ * nrows + row_in) * NW + (tt_ >> 6)];
       }
-      if (tt_ < npieces && !next_zero) async_load16(mp, mat_tab[tt_], gates + bn_ * gate_stride);
       if (!init) {
         const uint32_t base_ = lane_tab[row_in * 64u + (tt_ & 63u)] ^ in_uni;
         const double2* src_ = in + (bn_ >= share.fresh_begin ? 0ll : bn_) * state_stride;
@@ -327,7 +411,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
         for (int i = 0; i < 8; ++i) {
           const double2 x = tile[slot_t ^ comb3(i, drain_step)];
           const uint32_t off = off0 ^ comb3(i, out_step_n);
-          if (fin) async_store8(off, x.x * x.x + x.y * x.y, pdst);
+          if (fin) async_store8(off, (x.x * x.x + x.y * x.y) * scale, pdst);
           else async_store16(off, (d2_t){x.x, x.y}, dst);
         }
       }
@@ -344,13 +428,9 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
         for (uint32_t i = t; i < nsign * NW; i += T) mask_tab[i] = MASK[(size_t)gnx * nsign * NW + i];
       }
     }
-    // ---- the next tile's matrices (the oldest loads in flight) -> the other buffer ----
+    // (trip -1 issued no stores: the first real trip's vmcnt(8) would let its 8 loads pass -- wait for them here)
     if (!real) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (init || zslots) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (fewer than 8 loads in flight: all but the stores)
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    asm volatile("" : "+v"(mp));
-    if (t < npieces) mats_next[t] = make_double2(mp.x, mp.y);
-    __syncthreads();   // the tile is overwritten by the next trip; its matrices and table rows are in place
+    __syncthreads();   // the tile is overwritten by the next trip; the table rows are in place
   }
 #undef BORNVI_RUN_STAGE8
 }

@@ -1142,7 +1142,7 @@ bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg
   for (int i = 0; i < plan.n_passes; ++i) {
     const uint32_t* P = plan.words.data() + plan.pass_off[i];
     const uint32_t nst = P[PW_NSTAGES];
-    if (nst > (uint32_t)MAX_STAGES || nst * 12u > T) return fail("more matrix pieces than threads");
+    if (nst > (uint32_t)MAX_STAGES) return fail("too many stages");
     auto tbyte = [&](int table, int j) { return (P[table + (j >> 2)] >> (8 * (j & 3))) & 0xffu; };
     auto thalf = [&](int table, int j) { return (P[table + (j >> 1)] >> (16 * (j & 1))) & 0xffffu; };
     const uint32_t pflags = P[PW_FLAGS];
@@ -1184,20 +1184,26 @@ bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg
       uint32_t* CS = W.data() + hb + CH_WORDS + (size_t)s * CS_WORDS;
       CS[CS_KIND] = ngt | ((sflags & STAGE_SIGN_PRE) ? 8u : 0u) | ((sflags & STAGE_SIGN_POST) ? 16u : 0u);
       CS[CS_CROSS] = (sflags & STAGE_CROSS_READ) ? 1u : 0u;
-      for (int b = 0; b < 3; ++b) { CS[CS_RB + b] = S[16 + (1 << b)] << 4; CS[CS_WB + b] = S[32 + (1 << b)] << 4; }
+      for (int b = 0; b < 3; ++b) {
+        CS[CS_RB + b] = S[16 + (1 << b)] << 4; CS[CS_WB + b] = S[32 + (1 << b)] << 4;
+        CS[CS_MAT + b] = (fi[b] != 0xffffu ? fi[b] : 0u) * 64u;
+      }
       for (int j = 0; j < 8; ++j) {
         uint32_t lr = 0, lw = 0;
         for (int b = 0; b < 3; ++b) if (j >> b & 1) { lr ^= S[16 + (1 << b)]; lw ^= S[32 + (1 << b)]; }
         if (lr != S[16 + j] || lw != S[32 + j]) return fail("slot offsets not linear in the slot number");
       }
     }
-    // ---- matrix pieces: piece p = (stage, register bit, 16-byte quarter) ----
+    // ---- the pass's fused matrices (byte offsets in one circuit's gate array), in stage order ----
     W[hb + CH_MAT_OFF] = (uint32_t)W.size() - hb;
-    for (uint32_t p2 = 0; p2 < nst * 12u; ++p2) {
-      const uint32_t st = p2 / 12u, rb = (p2 % 12u) >> 2;
-      const uint32_t w = P[PW_MATS + 2 * st + (rb >> 1)];
-      const uint32_t f = (rb & 1u) ? (w >> 16) : (w & 0xffffu);
-      W.push_back(((f != 0xffffu ? f : 0u) * 4u + (p2 & 3u)) << 4);
+    {
+      uint32_t nmat = 0;
+      for (uint32_t s = 0; s < nst; ++s) {
+        const uint32_t* S = SE[s].S;
+        const uint32_t fi[3] = {S[6] & 0xffffu, S[6] >> 16, S[7] & 0xffffu};
+        for (int b = 0; b < 3; ++b) if (fi[b] != 0xffffu) { W.push_back(fi[b] * 64u); ++nmat; }
+      }
+      W[hb + CH_NMAT] = nmat;
     }
     // ---- ordinary tile fill / drain steps ----
     for (int m = 0; m < 3; ++m) {

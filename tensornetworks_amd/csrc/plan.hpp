@@ -214,7 +214,8 @@ bool build_fast_tables(const Plan& plan, size_t max_bytes, FastTables& out);
 // with a 6-bit mask M per (tile row, sign row, wave): word ^= 0xffff (pre) / 0xffff0000 (post) where that parity is odd.
 // Layout of `words` per pass, at pass_off[i]:
 //   header CH_WORDS words, then nstages stage headers of CS_WORDS words, then
-//   MAT[nstages * 12]: byte offset, in one circuit's gate array, of the 16-byte matrix piece thread p stages into LDS
+//   MAT[CH_NMAT]: byte offsets, in one circuit's gate array, of the fused matrices the pass uses (the kernel reads them with
+//   scalar loads, 64 bytes each, and touches the next tile's a trip ahead)
 //   LANE[nrows][64], UNI[2^(n-k)][nrows][nwaves], MASK[2^(n-k)][nsign][nwaves] (pre mask | post mask << 8)
 // rows: 0 .. nstages-1: read slot | write slot << 16 of the stage;  then one row per stage carrying a sign (in stage
 // order): pre sign bits | post sign bits << 16;  then CR_IN_D, CR_IN_N, CR_OUT_D, CR_OUT_N, CR_SLOT.
@@ -223,6 +224,7 @@ enum CompactHeader : int {
   CH_DIRECT,        // bit 0: the first stage can take its amplitudes straight from HBM (row CR_IN_D), bit 1: the last stage can store straight to HBM
   CH_ZINFO,         // support of |0..0>, as FH_ZINFO
   CH_NWAVES, CH_MAT_OFF, CH_LANE_OFF, CH_UNI_OFF, CH_MASK_OFF,     // offsets from the pass's header
+  CH_NMAT = 30,         // fused matrices of the pass (entries of MAT)
   CH_IN_STEP_D = 12,    // [3] byte offsets xor-ed into a thread's CR_IN_D word for bit m of the element number (= slot number of the first stage)
   CH_IN_STEP_N = 15,    // [3] the same for the ordinary tile fill (row CR_IN_N): 16 << phys-in position of enumeration bit k-3+m
   CH_FILL_STEP = 18,    // [3] LDS slot masks of those enumeration bits (tile fill; thread part: low half of row CR_SLOT)
@@ -231,18 +233,19 @@ enum CompactHeader : int {
   CH_OUT_STEP_N = 27,   // [3] byte offsets of the top 3 out-enumeration bits (row CR_OUT_N)
   CH_WORDS = 32
 };
-enum CompactStage : int { CS_KIND = 0, CS_CROSS, CS_RB = 2, CS_WB = 5, CS_WORDS = 8 };
+// stage header: kind (fused gates on register bits 0 .. ng-1 | pre sign << 3 | post sign << 4), cross-read flag, byte offsets
+// xor-ed into the LDS read / write address for the bits of the slot number, byte offset of register bit i's matrix in one
+// circuit's gate array
+enum CompactStage : int { CS_KIND = 0, CS_CROSS, CS_RB = 2, CS_WB = 5, CS_MAT = 8, CS_WORDS = 12 };
 enum CompactRow : int { CR_IN_D = 0, CR_IN_N, CR_OUT_D, CR_OUT_N, CR_SLOT, CR_EXTRA = 5 };   // + nstages + nsign
-constexpr int R3_MATS_BYTES = 3 * 64;   // LDS bytes of one stage's three 2x2 complex matrices
 struct CompactTables {
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;
   int max_rows = 0, max_sign = 0, max_stages = 0;
-  // LDS of circuit_pass_r3_kernel: tile | matrices (two buffers) | matrix-piece offsets | LANE | UNI (one tile row) | MASK | prefetch words
+  // LDS of circuit_pass_r3_kernel: tile | LANE | UNI (one tile row) | MASK
   size_t lds_bytes(int k) const {
     const size_t nw = ((size_t)1 << (k - 3)) / 64;
-    return ((size_t)16 << k) + 2 * (size_t)max_stages * R3_MATS_BYTES + (size_t)max_stages * 12 * 4 + (size_t)max_rows * 64 * 4 +
-           (size_t)max_rows * nw * 4 + (size_t)(max_sign > 0 ? max_sign : 1) * nw * 4 + 2 * nw * 4 + 64;
+    return ((size_t)16 << k) + (size_t)max_rows * 64 * 4 + (size_t)max_rows * nw * 4 + (size_t)(max_sign > 0 ? max_sign : 1) * nw * 4 + 64;
   }
 };
 // false (with msg) when the plan is not eligible (r != 3, tiles below 2^9, more matrix pieces than threads) or when a table

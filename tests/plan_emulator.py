@@ -370,7 +370,8 @@ def plan_stats(W):
 # ---- compact tables (plan.hpp: CompactTables; kernels_circuit8.hip: circuit_pass_r3_kernel) -----------------------
 CH_NSTAGES, CH_NROWS, CH_NSIGN, CH_SIGN_PRE, CH_SIGN_POST, CH_DIRECT, CH_ZINFO, CH_NWAVES, CH_MAT_OFF, CH_LANE_OFF, CH_UNI_OFF, CH_MASK_OFF = range(12)
 CH_IN_STEP_D, CH_IN_STEP_N, CH_FILL_STEP, CH_DRAIN_STEP, CH_OUT_STEP_D, CH_OUT_STEP_N, CH_WORDS = 12, 15, 18, 21, 24, 27, 32
-CS_KIND, CS_CROSS, CS_RB, CS_WB, CS_WORDS = 0, 1, 2, 5, 8
+CS_KIND, CS_CROSS, CS_RB, CS_WB, CS_MAT, CS_WORDS = 0, 1, 2, 5, 8, 12
+CH_NMAT = 30
 CR_IN_D, CR_IN_N, CR_OUT_D, CR_OUT_N, CR_SLOT = range(5)
 
 
@@ -428,12 +429,17 @@ def run_plan_compact(W, compact, mats, state_in=None, direct=3, zero_support=Tru
         steps = {name: [H[base + m] for m in range(3)] for name, base in
                  (("in_d", CH_IN_STEP_D), ("in_n", CH_IN_STEP_N), ("fill", CH_FILL_STEP), ("drain", CH_DRAIN_STEP),
                   ("out_d", CH_OUT_STEP_D), ("out_n", CH_OUT_STEP_N))}
-        # the matrix pieces a workgroup stages: piece p of (stage, register bit) comes from fused gate (offset >> 6)
-        mat_of = {}
-        for p2 in range(nst * 12):
-            off = int(Cw[C + H[CH_MAT_OFF] + p2])
-            assert (off >> 4) & 3 == p2 & 3
-            mat_of[(p2 // 12, (p2 % 12) >> 2)] = off >> 6
+        # the fused matrix of (stage, register bit): byte offset in one circuit's gate array (64 bytes per matrix); the
+        # pass's list of matrices (touched a trip ahead) holds exactly those
+        mat_of, listed = {}, []
+        for s_ in range(nst):
+            ng_ = int(Cw[C + CH_WORDS + s_ * CS_WORDS + CS_KIND]) & 7
+            for gi in range(ng_):
+                off = int(Cw[C + CH_WORDS + s_ * CS_WORDS + CS_MAT + gi])
+                assert off % 64 == 0
+                mat_of[(s_, gi)] = off >> 6
+                listed.append(off)
+        assert listed == [int(x) for x in Cw[C + H[CH_MAT_OFF]: C + H[CH_MAT_OFF] + int(Cw[C + CH_NMAT])]]
         out = np.zeros(N, dtype=np.complex128)
         probs = np.zeros(N)
         written = np.zeros(N, dtype=np.int64)
