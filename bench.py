@@ -564,6 +564,31 @@ def bench_adversarial(args, dev, D):
     D.close()
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` started as ONE process (no WORLD_SIZE / RANK in the environment): run the N ranks as
+    children of `python -m torch.distributed.run` -- the launch line the driver itself uses -- on a free local port, relay
+    their output and return their exit code.  This process must not have initialised the GPU (it has not: nothing before
+    the call touches HIP), and it never replaces itself (no exec): it waits for the child."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    if torch.cuda.device_count() < n_ranks and "BORNVI_DIST_BACKEND" not in env:
+        # fewer GPUs than ranks (a rehearsal on a one-GPU box): RCCL cannot put two ranks on one device
+        env["BORNVI_DIST_BACKEND"] = "gloo"
+        print(f"[bench] {n_ranks} ranks on {torch.cuda.device_count()} GPU(s): rehearsal with the gloo backend", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print("[bench] starting ranks:", " ".join(cmd), file=sys.stderr)
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        raise SystemExit(rc)
+    return rc
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -593,7 +618,19 @@ def main(argv=None):
     ap.add_argument("--overlap", type=int, default=0,
                     help="how circuits and contraction share the GPU: 0 in sequence (default), 1 second plain stream, 2 two "
                          "CU-masked streams (half the CUs each), -1 measured choice between 0 and 2 (choose_overlap)")
+    ap.add_argument("--no-dist-selftest", action="store_true", help="N > 1: skip the sharded-vs-unsharded check (on by default)")
     args = ap.parse_args(argv)
+
+    # ---- N > 1 without a rendezvous in the environment: start the N ranks ourselves.  The parent never touches the GPU
+    # (no HIP call before this point: `import torch` and argparse only); the ranks are fresh child processes of
+    # torch.distributed.run, rank 0's JSON line passes through on stdout, the exit code is the children's. ----
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+                         "start one rank per GPU (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), or "
+                         "run `python bench.py --gpus N` without a rendezvous in the environment and it starts them itself")
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -603,8 +640,8 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     D = Dist(dev)
     world, rank = D.world, D.rank
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if world > 1 and not args.no_dist_selftest:
+        args.dist_selftest = True
 
     from tensornetworks_amd import backend
     if args.tile_bits:

@@ -29,6 +29,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BORNVI_VERSION 100 /* 0.1.0 */
 
@@ -84,6 +88,10 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
  * bornvi_paramshift_probs* a shifted circuit starts from the base circuit's state at the first pass
  * its parameter touches instead of |0..0> -- the rows are bit-identical, fewer passes are run). */
 int bornvi_set_option(bornvi_handle h, const char* name, long long value);
+/* Current value of a planner / engine option ("reg_wires": 3 = the pass kernel with 8 amplitudes per thread and four waves
+ * per SIMD where the plan is eligible, 4 = 16 per thread; "read_map", "tile_bits", "tile_bits_multi", "low_bits",
+ * "prefix_share", "grad_engine", "fast_path", "direct_stages", "zero_support", "alternate_walk", "batched_quadform"). */
+int bornvi_get_option(bornvi_handle h, const char* name, long long* value);
 
 /* num_ansatz_params (quantum_born_machine.py:31-38) and gate count of the QNode. */
 int bornvi_num_params(int ansatz, int n, int layers);
@@ -193,6 +201,13 @@ size_t bornvi_stein_quadform_workspace_bytes(bornvi_handle h, int n, int B);
 int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B,
                           double* ksd2, double* Y, void* workspace, size_t workspace_bytes,
                           bornvi_stream stream);
+/* The same for a K with row pitch `ld` doubles (bornvi_stein_gram_build_rows_ld; even, 2^n <= ld <= 2^n + 4096): the
+ * trainer's padded K_p serves the batched contraction too (no second 32 GiB copy).  With ld > 2^n only the batched
+ * matrix-core form exists (n >= 8, B >= 2, option "batched_quadform" = 1), otherwise BORNVI_ERR_UNSUPPORTED; B = 1 on
+ * a padded K: bornvi_stein_quadform_sym_ld. */
+int bornvi_stein_quadform_ld(bornvi_handle h, int n, const double* K, long long ld, const double* Q, int B,
+                             double* ksd2, double* Y, void* workspace, size_t workspace_bytes,
+                             bornvi_stream stream);
 
 /* Same result for a SYMMETRIC K (every K from bornvi_stein_gram_build is bitwise symmetric): reads
  * only the upper triangle, i.e. half the HBM traffic of bornvi_stein_quadform; deterministic (column
@@ -204,7 +219,8 @@ int bornvi_stein_quadform_sym(bornvi_handle h, int n, const double* K, const dou
                               double* ksd2, double* y, void* workspace, size_t workspace_bytes,
                               bornvi_stream stream);
 
-/* The same for a K with row pitch `ld` doubles (bornvi_stein_gram_build_rows_ld). */
+/* The same for a K with row pitch `ld` doubles (bornvi_stein_gram_build_rows_ld).  Matrices of fewer than two 256-row
+ * bands (n < 9) run the full-matrix kernel, which takes dense rows only: ld > 2^n there is BORNVI_ERR_UNSUPPORTED. */
 int bornvi_stein_quadform_sym_ld(bornvi_handle h, int n, const double* K, long long ld, const double* q,
                                  double* ksd2, double* y, void* workspace, size_t workspace_bytes,
                                  bornvi_stream stream);
@@ -309,6 +325,9 @@ long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits
 long long bornvi_plan_compact_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out,
                                        size_t cap_words, uint32_t* pass_off_out, int cap_passes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

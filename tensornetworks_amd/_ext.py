@@ -39,6 +39,7 @@ _PROTOS = {
     "bornvi_destroy": (None, [C.c_void_p]),
     "bornvi_last_error": (C.c_char_p, [C.c_void_p]),
     "bornvi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
+    "bornvi_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]),
     "bornvi_num_params": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bornvi_num_gates": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bornvi_circuit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -74,6 +75,8 @@ _PROTOS = {
     "bornvi_stein_quadform_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "bornvi_stein_quadform": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_stein_quadform_ld": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_stein_quadform_sym_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "bornvi_stein_quadform_sym": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_size_t, C.c_void_p]),

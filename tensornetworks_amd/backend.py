@@ -148,6 +148,13 @@ def set_option(dev, name, value):
     h.call("bornvi_set_option", name.encode(), int(value))
 
 
+def get_option(dev, name):
+    """Current value of a planner / engine option of this device's handle (bornvi_get_option)."""
+    v = C.c_longlong(0)
+    _ext.handle_for(dev).call("bornvi_get_option", name.encode(), C.byref(v))
+    return int(v.value)
+
+
 def set_engine_option(dev, name, value):
     """Options that do not change plans or workspace sizes (e.g. "circuit_cus"): no cache invalidation."""
     _ext.handle_for(dev).call("bornvi_set_option", name.encode(), int(value))
@@ -448,7 +455,8 @@ def stein_quadform(K, Q, n, want_y=True):
     dev = K.device
     h = _ext.handle_for(dev)
     _chk_n(n, 1, 17)
-    _chk(K, torch.float64, dev, "K", 1 << (2 * n))
+    # K: dense [2^n, 2^n], or the [:, :2^n] view of a padded [2^n, ld] buffer (the trainer's K_p, stein_gram(ld=...))
+    ld = _chk_matrix(K, 1 << n, 1 << n, dev, "K") if K.dim() == 2 else (_chk(K, torch.float64, dev, "K", 1 << (2 * n)) or (1 << n))
     if Q.numel() % (1 << n):
         raise BornviError("Q: element count is not a multiple of 2^n")
     Q2 = Q.reshape(-1, 1 << n)
@@ -457,7 +465,7 @@ def stein_quadform(K, Q, n, want_y=True):
     ksd2 = torch.empty(B, dtype=torch.float64, device=dev)
     Y = torch.empty_like(Q2) if want_y else None
     ws = _ws(dev, h.size("bornvi_stein_quadform_workspace_bytes", n, B), "qf")
-    h.call("bornvi_stein_quadform", n, _ptr(K), _ptr(Q2), B, _ptr(ksd2), _ptr(Y) if want_y else None, _ptr(ws),
+    h.call("bornvi_stein_quadform_ld", n, _ptr(K), ld, _ptr(Q2), B, _ptr(ksd2), _ptr(Y) if want_y else None, _ptr(ws),
            ws.numel(), _ext.stream_ptr(dev))
     return ksd2, Y
 

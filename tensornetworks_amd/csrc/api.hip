@@ -551,6 +551,24 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   return BORNVI_OK;
 }
 
+int bornvi_get_option(bornvi_handle h, const char* name, long long* value) {
+  if (!h || !name || !value) return BORNVI_ERR_INVALID;
+  if (!std::strcmp(name, "reg_wires")) *value = h->opt.r;
+  else if (!std::strcmp(name, "read_map")) *value = h->opt.read_map ? 1 : 0;
+  else if (!std::strcmp(name, "tile_bits")) *value = h->opt.kmax;
+  else if (!std::strcmp(name, "tile_bits_multi")) *value = h->opt.kmulti;
+  else if (!std::strcmp(name, "low_bits")) *value = h->opt.lo;
+  else if (!std::strcmp(name, "prefix_share")) *value = h->prefix_share;
+  else if (!std::strcmp(name, "grad_engine")) *value = h->grad_engine;
+  else if (!std::strcmp(name, "fast_path")) *value = h->fast_path;
+  else if (!std::strcmp(name, "direct_stages")) *value = h->direct_stages;
+  else if (!std::strcmp(name, "zero_support")) *value = h->zero_support;
+  else if (!std::strcmp(name, "alternate_walk")) *value = h->alternate_walk;
+  else if (!std::strcmp(name, "batched_quadform")) *value = h->batched_quadform;
+  else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
+  return BORNVI_OK;
+}
+
 int bornvi_num_params(int ansatz, int n, int layers) { return num_params(ansatz, n, layers); }
 
 int bornvi_num_gates(int ansatz, int n, int layers) {
@@ -776,11 +794,12 @@ int bornvi_stein_quadform_rows(bornvi_handle h, int n, const double* K_rows, lon
   return BORNVI_OK;
 }
 
-int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B, double* ksd2, double* Y,
-                          void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+int bornvi_stein_quadform_ld(bornvi_handle h, int n, const double* K, long long ld, const double* Q, int B, double* ksd2,
+                             double* Y, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
   if (!h) return BORNVI_ERR_INVALID;
   if (!K || !Q || !ksd2 || B < 0) return fail(h, BORNVI_ERR_INVALID, "bad argument");
   if (!valid_n_for_dense(n)) return fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17");
+  if (!valid_ld(n, ld)) return fail(h, BORNVI_ERR_INVALID, "leading dimension must be even, >= 2^n and <= 2^n + 4096");
   if (!workspace || workspace_bytes < bornvi_stein_quadform_workspace_bytes(h, n, B))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small");
   DEVICE_SCOPE(h);
@@ -788,12 +807,20 @@ int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double*
   if (quadform_batched_supported(n, B) && h->batched_quadform) {
     // one pass over K on the matrix cores (kernels_batched.hip) instead of B passes of the HBM-bound GEMV
     double* Yw = Y ? Y : (double*)((char*)workspace + align_up(quadform_partials(N) * sizeof(double), 256));
-    HIPCHK(h, launch_quadform_batched(n, K, Q, B, Yw, ksd2, (hipStream_t)stream));
+    HIPCHK(h, launch_quadform_batched(n, K, ld, Q, B, Yw, ksd2, (hipStream_t)stream));
     return BORNVI_OK;
   }
+  if (ld != N) return fail(h, BORNVI_ERR_UNSUPPORTED, "a padded K needs the batched form (n >= 8, B >= 2, option batched_quadform = 1); "
+                                                      "B = 1: bornvi_stein_quadform_sym_ld");
   for (int b = 0; b < B; ++b)
     HIPCHK(h, launch_quadform(n, K, 0, N, Q + b * N, Y ? Y + b * N : nullptr, ksd2 + b, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;
+}
+
+int bornvi_stein_quadform(bornvi_handle h, int n, const double* K, const double* Q, int B, double* ksd2, double* Y,
+                          void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (n < 0 || n > 40) return h ? fail(h, BORNVI_ERR_UNSUPPORTED, "dense Gram supports 1 <= n <= 17") : BORNVI_ERR_INVALID;
+  return bornvi_stein_quadform_ld(h, n, K, 1ll << n, Q, B, ksd2, Y, workspace, workspace_bytes, stream);
 }
 
 size_t bornvi_stein_quadform_sym_workspace_bytes(bornvi_handle h, int n) {
@@ -811,6 +838,8 @@ int bornvi_stein_quadform_sym_ld(bornvi_handle h, int n, const double* K, long l
   if (!workspace || workspace_bytes < bornvi_stein_quadform_sym_workspace_bytes(h, n) || ((uintptr_t)workspace & 15))
     return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
   if ((uintptr_t)K & 15) return fail(h, BORNVI_ERR_INVALID, "K must be 16-byte aligned");
+  if (n < quadform_sym_min_n() && ld != (1ll << n))
+    return fail(h, BORNVI_ERR_UNSUPPORTED, "a padded K needs at least two 256-row bands (n >= 9); smaller matrices are contracted dense");
   DEVICE_SCOPE(h);
   HIPCHK(h, launch_quadform_sym(n, K, ld, q, y, ksd2, (double*)workspace, (hipStream_t)stream));
   return BORNVI_OK;

@@ -10,10 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 REPO = os.path.dirname(PKG)
 SOURCES = ["api.hip", "kernels_circuit.hip", "kernels_circuit8.hip", "kernels_stein.hip", "kernels_batched.hip", "kernels_adjoint.hip", "plan.cpp"]
-HEADERS = [os.path.join(HERE, h) for h in ("plan.hpp", "kernels.hpp", "circuit_dev.hpp")] + [os.path.join(REPO, "include", "bornvi.h")]
+HEADERS = [os.path.join(HERE, h) for h in ("plan.hpp", "kernels.hpp", "circuit_dev.hpp", "exports.map")] + [os.path.join(REPO, "include", "bornvi.h")]
 OUT = os.path.join(PKG, "libbornvi_hip.so")
 OBJ = os.path.join(HERE, "_obj")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE,
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-I" + os.path.join(REPO, "include"), "-I" + HERE,
          "-Rpass-analysis=kernel-resource-usage"]
 
 # Register-allocation guard rails.  The hot kernels sit a few registers below a cliff: a small source edit has more than
@@ -65,7 +65,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     check_resources(objs, verbose)
-    run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs)
+    run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,--version-script=" + os.path.join(HERE, "exports.map"), "-o", OUT] + objs)
     return OUT
 
 

@@ -84,7 +84,7 @@ hipError_t launch_quadform(int n, const double* K, long long row_begin, long lon
                            double* y_or_null, double* ksd2, double* partials, hipStream_t st);
 // batched Y = K Q^T on the matrix cores (kernels_batched.hip): n >= 8, B >= 2; Y must be given ([B, 2^n])
 bool quadform_batched_supported(int n, int B);
-hipError_t launch_quadform_batched(int n, const double* K, const double* Q, int B, double* Y, double* ksd2, hipStream_t st);
+hipError_t launch_quadform_batched(int n, const double* K, long long ld, const double* Q, int B, double* Y, double* ksd2, hipStream_t st);
 size_t quadform_sym_workspace_doubles(int n);
 hipError_t launch_quadform_sym(int n, const double* K, long long ld, const double* q, double* y_or_null, double* ksd2,
                                double* ws, hipStream_t st);

@@ -27,7 +27,7 @@ typedef double qb_d4 __attribute__((ext_vector_type(4)));
 typedef double qb_d2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(QB_THREADS) void quadform_batched_kernel(const double* __restrict__ K, const double* __restrict__ Q,
-                                                                     double* __restrict__ Y, long long N, int B) {
+                                                                     double* __restrict__ Y, long long N, long long ld, int B) {
   extern __shared__ double qb_lds[];
   double* __restrict__ As = qb_lds;                                   // [2][QB_BM][QB_PITCH]
   double* __restrict__ Bs = qb_lds + 2 * QB_BM * QB_PITCH;            // [2][QB_BN][QB_PITCH]
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(QB_THREADS) void quadform_batched_kernel(const doub
   const int b_blk = blockIdx.x * QB_BN;
   // global -> register staging: 16 bytes per thread and load; A: 4 loads (rows t/8 + 64 u), B: 2 loads (vectors t/8 + 64 u)
   const int lrow = t >> 3, lk = (t & 7) * 2;
-  const double* __restrict__ Ag = K + (i_blk + lrow) * N + lk;
+  const double* __restrict__ Ag = K + (i_blk + lrow) * ld + lk;        // (ld: row pitch of K in doubles, >= N)
   const double* __restrict__ Bg = Q + (long long)(b_blk + lrow) * N + lk;
   bool bok[2];
 #pragma unroll
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(QB_THREADS) void quadform_batched_kernel(const doub
   auto load_tiles = [&](long long k0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const double* p = Ag + (long long)(64 * u) * N + k0;
+      const double* p = Ag + (long long)(64 * u) * ld + k0;
       ra[u].x = __builtin_nontemporal_load(p); ra[u].y = __builtin_nontemporal_load(p + 1);
     }
 #pragma unroll
@@ -128,18 +128,18 @@ __global__ __launch_bounds__(1024) void rowdot_kernel(const double* __restrict__
 
 bool quadform_batched_supported(int n, int B) { return n >= 8 && n <= 17 && B >= 2; }
 
-hipError_t launch_quadform_batched(int n, const double* K, const double* Q, int B, double* Y, double* ksd2, hipStream_t st) {
+hipError_t launch_quadform_batched(int n, const double* K, long long ld, const double* Q, int B, double* Y, double* ksd2, hipStream_t st) {
   const long long N = 1ll << n;
   const size_t lds = (size_t)2 * (QB_BM + QB_BN) * QB_PITCH * sizeof(double);
-  static bool prepared = false;
-  if (!prepared) {
+  // (the attribute is per device and cheap to set: no process-wide "done" flag that a second device or a second thread
+  // could find set before its own call went through)
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quadform_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    prepared = true;
   }
   // x = vector block (fastest): the workgroups that share a block of K rows are dispatched together
   dim3 grid((unsigned)((B + QB_BN - 1) / QB_BN), (unsigned)(N / QB_BM));
-  quadform_batched_kernel<<<grid, QB_THREADS, lds, st>>>(K, Q, Y, N, B);
+  quadform_batched_kernel<<<grid, QB_THREADS, lds, st>>>(K, Q, Y, N, ld, B);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   rowdot_kernel<<<(unsigned)B, 1024, 0, st>>>(Q, Y, N, ksd2);

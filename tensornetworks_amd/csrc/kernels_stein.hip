@@ -292,11 +292,9 @@ static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable
   if (row_end <= row_begin) return hipSuccess;
   constexpr GramFactorPitch g = gram_pitch(NB);
   const size_t lds = (size_t)(GM_ROWS + 4 * 16) * g.rowpitch * sizeof(double);
-  static bool prepared = false;
-  if (!prepared) {
+  {   // (per device and cheap: set on every launch rather than behind a process-wide flag)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_mfma_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    prepared = true;
   }
   const long long cols = N < GM_COLS ? N : GM_COLS;
   dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - row_begin + GM_ROWS - 1) / GM_ROWS));

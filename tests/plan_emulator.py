@@ -479,7 +479,7 @@ def run_plan_compact(W, compact, mats, state_in=None, direct=3, zero_support=Tru
                 CS = C + CH_WORDS + s * CS_WORDS
                 kind = int(Cw[CS + CS_KIND])
                 ng, pre, post = kind & 7, (kind >> 3) & 1, (kind >> 4) & 1
-                assert ng <= 3 and int(Cw[CS + CS_CROSS]) == 0
+                assert ng <= 3 and int(Cw[CS + CS_CROSS]) == 0, "the sequential emulator cannot order a cross-group read"
                 rb = [int(Cw[CS + CS_RB + b]) for b in range(3)]
                 wb = [int(Cw[CS + CS_WB + b]) for b in range(3)]
                 rw = word(s, g)

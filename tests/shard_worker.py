@@ -132,7 +132,14 @@ def cold_batch(rank, world_size, port, n, L, read_map, out_dir):
         th = (0.1 * torch.randn(P, generator=g, dtype=torch.float32)).double().to(dev)
         full = be.paramshift_probs("hardware_efficient", n, L, th, 0, P, include_base=True)
         worst = float((full.sum(dim=1) - 1.0).abs().max())
-        np.savez(os.path.join(out_dir, f"cold{rank}.npz"), worst=np.float64(worst))
+        # the base row and six shifted rows go back to the parent, which compares them with the oracle's C port (a
+        # normalised wrong row would pass the sum check); a digest of every row lets two cold runs be compared bitwise
+        picks = [0, P // 2 + 7, P - 1]
+        rows = [0] + [r for p_ in picks for r in (1 + 2 * p_, 2 + 2 * p_)]
+        import hashlib
+        digest = hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest()
+        np.savez(os.path.join(out_dir, f"cold{rank}.npz"), worst=np.float64(worst), rows=full[rows].cpu().numpy(),
+                 theta=th.cpu().numpy(), picks=np.array(picks), digest=np.array(digest))
     except BaseException:
         with open(os.path.join(out_dir, f"rank{rank}.err"), "w") as f:
             traceback.print_exc(file=f)

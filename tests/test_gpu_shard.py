@@ -109,6 +109,27 @@ def test_bench_dist_selftest_two_ranks(dev, tmp_path):
     assert not [l for l in open(tmp_path / "bench1.out").read().splitlines() if l.startswith("{")]   # rank 0 prints
 
 
+def test_bench_starts_its_own_ranks(dev, tmp_path):
+    """`python bench.py --gpus 2` with NO rendezvous in the environment (the way the driver starts the --gpus 1 run): the
+    process starts the two ranks itself before touching the GPU (a child `python -m torch.distributed.run`), relays rank
+    0's JSON line and the children's exit code.  gloo here because the ranks share this box's one GPU (bench.py picks
+    it when there are fewer GPUs than ranks); the sharded-vs-unsharded self-test is on by default for N > 1."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "BORNVI_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "n12_L4_dense", "--no-cpu-baseline", "--no-gate-bench", "--no-extras", "--series", "none",
+                        "--repeats", "1"], env=env, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["dist_backend"] == "gloo"
+    assert rec["dist_selftest"]["ok"] and rec["dist_selftest"]["ranks"] == 2
+
+
 def test_rccl_group_of_one_runs_the_collective_wrappers(dev, tmp_path):
     """RCCL itself (backend 'nccl', `device_id=` as bench.py passes it) on the one GPU of the box: a one-rank group runs
     the all-gather / all-reduce wrappers and bench.py's MAX-reduce, object gather and barrier on float64 device
@@ -123,7 +144,22 @@ def test_cold_process_runs_the_full_n20_batch_correctly(dev, tmp_path, read_map)
     """Two fresh processes each run BASELINE config 4's batch (n = 20, L = 8, 961 circuits) as their FIRST GPU work:
     every row must sum to 1.  (A stage that read across thread groups without a barrier was right in every warm run
     and wrong in five of eight cold ones.)"""
+    from oracle import cpu_port as cp, circuit as oc
+    want, digests = None, []
     for trial in range(2):
         codes = run_ranks(shard_worker.cold_batch, 1, (20, 8, read_map, str(tmp_path)), timeout=300)
         assert codes == [0], (codes, _errors(tmp_path))
-        assert float(np.load(tmp_path / "cold0.npz")["worst"]) < 1e-12
+        res = np.load(tmp_path / "cold0.npz")
+        assert float(res["worst"]) < 1e-12
+        digests.append(str(res["digest"]))
+        if want is None and cp.available():          # base row + six shifted rows against the C port (computed once)
+            th = res["theta"]
+            ts = [th.copy()]
+            for p_ in res["picks"]:
+                for sgn in (+1, -1):
+                    t2 = th.copy(); t2[int(p_)] += sgn * np.pi / 2
+                    ts.append(t2)
+            want = cp.circuit_probs("hardware_efficient", 20, 8, np.stack(ts))
+        if want is not None:
+            np.testing.assert_allclose(res["rows"], want, rtol=1e-9, atol=1e-17)
+    assert digests[0] == digests[1]                  # the whole 961-row batch: bitwise the same in both cold processes

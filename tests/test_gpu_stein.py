@@ -310,3 +310,38 @@ def test_batched_quadform_on_matrix_cores(be, dev, n, B):
     assert none is None and torch.equal(k_only, k_mfma)
     k_again, Y_again = be.stein_quadform(K, Q, n)       # deterministic
     assert torch.equal(Y_again, Y_mfma) and torch.equal(k_again, k_mfma)
+
+
+def test_batched_quadform_on_the_trainers_padded_gram(be, dev):
+    """bornvi_stein_quadform_ld: the batched matrix-core contraction reads a K_p with a row pitch (the trainer builds
+    K_p with pitch 2^n + 32 for n >= 14, bornvi_stein_gram_ld) -- the KSD at every shifted point needs no second dense
+    copy.  Y and ksd2 bitwise equal to the run on the dense copy of the same matrix; a padded K without the batched form
+    (B = 1, or batched_quadform = 0) is refused, not misread."""
+    from tensornetworks_amd._ext import BornviError
+    n, B = 14, 130
+    N = 1 << n
+    bn, lat, obs, x = synthetic_network(n, 4)
+    S, _ = be.score_from_packed(pack_network(bn, lat, x), n, dev)
+    ld = be.gram_ld(n)
+    assert ld == N + 32
+    Kp = be.stein_gram(S, n, 1.0, ld=ld)
+    assert Kp.shape == (N, N) and Kp.stride(0) == ld
+    Kd = Kp.contiguous()
+    g = torch.Generator().manual_seed(5)
+    Q = torch.rand((B, N), generator=g, dtype=torch.float64).to(dev)
+    Q /= Q.sum(dim=1, keepdim=True)
+    k_d, Y_d = be.stein_quadform(Kd, Q, n)
+    k_p, Y_p = be.stein_quadform(Kp, Q, n)
+    assert torch.equal(Y_p, Y_d) and torch.equal(k_p, k_d)
+    with pytest.raises(BornviError, match="padded K"):
+        be.stein_quadform(Kp, Q[0], n)
+    try:
+        be.set_engine_option(dev, "batched_quadform", 0)
+        with pytest.raises(BornviError, match="padded K"):
+            be.stein_quadform(Kp, Q, n)
+    finally:
+        be.set_engine_option(dev, "batched_quadform", 1)
+    # the symmetric contraction refuses a pitch where it runs the dense full-matrix kernel (n < 9)
+    K8 = torch.zeros((256, 256 + 32), dtype=torch.float64, device=dev)[:, :256]
+    with pytest.raises(BornviError, match="padded K"):
+        be.stein_quadform_sym(K8, torch.full((256,), 1 / 256, dtype=torch.float64, device=dev), 8)

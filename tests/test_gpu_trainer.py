@@ -153,6 +153,81 @@ def test_full_size_step_n16(dev):
     np.testing.assert_allclose(grad_k.cpu().numpy(), grad_d.cpu().numpy(), rtol=1e-7, atol=1e-9 * grad_d.abs().max().item())
 
 
+def _c_port_step(ansatz, n, L, theta, S_host, dense):
+    """One KSD-gradient step of the oracle's C port (oracle/cpu_port.c): all 2P + 1 circuits, y = K_p q (dense rows in
+    blocks, or the matrix-free Kronecker form), loss = sqrt(max(q.y, 1e-12)), grad_p = (q+_p - q-_p) . y / (2 loss)."""
+    from oracle import cpu_port as cp
+    N, P = 1 << n, theta.size
+    probs, _ = cp.paramshift_probs(ansatz, n, L, theta, 0, P, include_base=True)
+    q = np.ascontiguousarray(probs[0])
+    if dense:
+        y = np.empty(N)
+        blk = max(1, min(N, (2 << 30) // (8 * N)))
+        for r0 in range(0, N, blk):
+            K_rows = cp.gram_rows(S_host, n, 1.0, r0, min(N, r0 + blk))
+            y[r0:r0 + blk], _ = cp.gemv_rows(K_rows, n, r0, min(N, r0 + blk), q)
+            del K_rows
+    else:
+        y, _ = cp.kron_matvec(S_host, q, n, 1.0)
+    loss = math.sqrt(max(float(q @ y), 1e-12))
+    grad = 0.5 * ((probs[1::2] - probs[2::2]) @ (y / loss))
+    return q, loss, grad
+
+
+def _bench_theta(P):
+    g = torch.Generator().manual_seed(0)
+    return (0.1 * torch.randn(P, generator=g, dtype=torch.float32))       # bench.py's theta0 (`small_random`)
+
+
+def test_config3_full_step_against_c_port(dev):
+    """BASELINE config 3 exactly as bench.py measures it (n = 16, L = 6, dense 2^16 x 2^16 Gram, theta0 of the bench):
+    q, the loss and the WHOLE 288-vector gradient of one training step against the oracle's C port -- all 577 circuits
+    and the full GEMV on the host (reference: ksd_vi_quantum.py:110-150, quantum_born_machine.py:58-87)."""
+    from oracle import cpu_port as cp
+    if not cp.available():
+        pytest.skip("oracle/_build/libcpu_port.so not built")
+    n, L = 16, 6
+    bn, lat, obs, x = synthetic_network(n, 0)
+    vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=0, gram_mode="dense")
+    P = vi.born_machine.num_ansatz_params
+    with torch.no_grad():
+        vi.born_machine.theta.copy_(_bench_theta(P).to(vi.born_machine.theta.device))
+    vi._prepare_stein(x)
+    loss, grad, q = vi.ksd_and_grad()
+    th = vi.born_machine.theta.detach().double().cpu().numpy()
+    q_o, loss_o, grad_o = _c_port_step("hardware_efficient", n, L, th, vi._S.cpu().numpy(), dense=True)
+    np.testing.assert_allclose(q.cpu().numpy(), q_o, rtol=1e-10, atol=1e-17)
+    assert abs(loss.item() - loss_o) <= 1e-12 * abs(loss_o), (loss.item(), loss_o)
+    np.testing.assert_allclose(grad.cpu().numpy(), grad_o, rtol=1e-8, atol=1e-9 * np.abs(grad_o).max())
+
+
+def test_config4_full_step_against_c_port(dev):
+    """BASELINE config 4 on one GPU (n = 20, L = 8, matrix-free contraction): loss and the whole 480-vector gradient of
+    one step against the C port's 961 circuits + Kronecker mat-vec (about half a minute of host time; run once)."""
+    from oracle import cpu_port as cp
+    if not cp.available():
+        pytest.skip("oracle/_build/libcpu_port.so not built")
+    n, L = 20, 8
+    bn, lat, obs, x = synthetic_network(n, 0)
+    vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=0, gram_mode="kron")
+    P = vi.born_machine.num_ansatz_params
+    with torch.no_grad():
+        vi.born_machine.theta.copy_(_bench_theta(P).to(vi.born_machine.theta.device))
+    vi._prepare_stein(x)
+    loss, grad, q = vi.ksd_and_grad()
+    th = vi.born_machine.theta.detach().double().cpu().numpy()
+    S_host = vi._S.cpu().numpy()
+    loss_v, grad_v, q_v = loss.item(), grad.cpu().numpy(), q.cpu().numpy()
+    del vi
+    from tensornetworks_amd import backend
+    backend.release_workspaces()
+    torch.cuda.empty_cache()
+    q_o, loss_o, grad_o = _c_port_step("hardware_efficient", n, L, th, S_host, dense=False)
+    np.testing.assert_allclose(q_v, q_o, rtol=1e-9, atol=1e-17)
+    assert abs(loss_v - loss_o) <= 1e-11 * abs(loss_o), (loss_v, loss_o)
+    np.testing.assert_allclose(grad_v, grad_o, rtol=1e-8, atol=1e-9 * np.abs(grad_o).max())
+
+
 def test_posterior_table_and_device_tvd(dev):
     """exact posterior and TVD as arrays on the device == the reference's dict forms
     (bayesian_network.py:148-253, utils.py:6-36), and train() tracks the same TVD with either."""

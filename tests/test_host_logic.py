@@ -74,6 +74,47 @@ def test_fast_tables_against_oracle(ansatz, n, L, kb):
     np.testing.assert_allclose(q, oc.probs(ansatz, n, L, th), rtol=0, atol=1e-13)
 
 
+@pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
+@pytest.mark.parametrize("n,L,kb,read_map", [(9, 1, 0, 0), (11, 2, 9, 0), (12, 3, 0, 1), (13, 2, 11, 0), (14, 2, 12, 1), (14, 3, 11, 1),
+                                             (15, 3, 12, 0)])
+def test_r3_plan_and_compact_tables_against_oracle(ansatz, n, L, kb, read_map):
+    """The plan with 3 register wires per stage (8 amplitudes per thread, circuit_pass_r3_kernel): (i) its stage headers
+    interpreted as the generic kernel does, (ii) its per-(tile row, thread) fast tables, (iii) its COMPACT tables -- every
+    word = LANE[row][lane] ^ UNI[tile row][row][wave], sign rows with the bilinear lane x (wave, tile row) term -- run exactly
+    as the kernel runs them (direct first / last stages on and off, support of |0..0> on and off) reproduce the oracle."""
+    from tensornetworks_amd import _ext
+    aid = _ext.ANSATZ_IDS[ansatz]
+    flags = kb | _ext.R3 | (0x100 if read_map else 0)
+    W = _ext.plan_words(aid, n, L, flags)
+    assert int(W[pe.PH_R]) == 3 and int(W[pe.PH_THREADS]) == max(64, 1 << (int(W[pe.PH_K]) - 3))
+    th = np.random.default_rng(n * 13 + L).uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
+    ref = oc.probs(ansatz, n, L, th)
+    mats = pe.fused_matrices(W, th)
+    np.testing.assert_allclose(pe.run_plan(W, mats), ref, rtol=0, atol=1e-13)
+    F, offs = _ext.plan_fast_words(aid, n, L, flags)
+    if F is not None:         # (the full tables keep the 16-amplitude kernel's rule "one matrix piece per thread"; the compact ones do not)
+        np.testing.assert_allclose(pe.run_plan(W, mats, fast=(F, offs)), ref, rtol=0, atol=1e-13)
+    Cw, coffs = _ext.plan_compact_words(aid, n, L, kb | (0x100 if read_map else 0))
+    assert Cw is not None and len(coffs) == int(W[pe.PH_NPASSES])
+    for direct, zs in ((3, True), (3, False), (0, False)):
+        if read_map:
+            continue          # (the compact emulator asserts stages without cross reads; those plans are covered on the GPU)
+        np.testing.assert_allclose(pe.run_plan_compact(W, (Cw, coffs), mats, direct=direct, zero_support=zs), ref, rtol=0, atol=1e-13)
+
+
+def test_r3_benchmark_sizes_are_eligible():
+    """BASELINE configs 3 and 4 under the 8-amplitude kernel: 2^13 tiles (1024 threads), compact tables within the CU's LDS
+    beside the tile; the planner's read map brings the stage count close to the bound of 3 gates per stage."""
+    from tensornetworks_amd import _ext
+    for n, L, gates in ((16, 6, 96), (20, 8, 160)):
+        for rm, max_stages in ((0, 10 ** 6), (0x100, gates // 3 + 8)):
+            W = _ext.plan_words(0, n, L, _ext.R3 | rm)
+            st = pe.plan_stats(W)
+            assert st["k"] == 13 and int(W[pe.PH_THREADS]) == 1024 and sum(st["stages"]) <= max_stages, st
+        Cw, coffs = _ext.plan_compact_words(0, n, L, 0)
+        assert Cw is not None and len(Cw) * 4 < 4 << 20
+
+
 def test_zero_support_masks_leave_out_only_zeros():
     """Support of |0..0> (fast tables, FH_ZINFO): the INIT pass leaves out tiles nobody reads, the pass behind it does
     not load slots known to be zero.  The emulator writes NaN where a left-out tile would have gone and computes with 0
@@ -326,3 +367,14 @@ def test_trainer_rejects_mismatched_latent_count():
     from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
     with pytest.raises(ValueError, match="must equal len"):
         KSDVariationalInference(get_sprinkler_network(False), ['C', 'S', 'R'], ['W'], qbm_num_latent_vars=4)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus(monkeypatch):
+    """bench.py --gpus N under a launcher that started a different number of ranks exits non-zero (before any GPU call)
+    instead of measuring the wrong job with a note on stderr."""
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"])
+    assert "WORLD_SIZE=3" in str(e.value)

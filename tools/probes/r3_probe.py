@@ -4,6 +4,7 @@ against 8 per thread (reg_wires = 3, circuit_pass_r3_kernel).  Rows must agree t
 order of the fused gates differs: not bitwise); times are per parameter-shift batch."""
 import hashlib
 import json
+import os
 import sys
 import time
 
@@ -42,6 +43,7 @@ def main():
         outs = {}
         for r in (4, 3):
             be.set_option(dev, "reg_wires", r)
+            be.set_option(dev, "read_map", int(os.environ.get("R3_READ_MAP", "1")) if r == 3 else 0)
             med, mn, out = batch_time("hardware_efficient", n, L)
             row[f"r{r}_ms"] = round(med, 4)
             row[f"r{r}_min_ms"] = round(mn, 4)
@@ -59,6 +61,7 @@ def main():
         be.release_workspaces()
         torch.cuda.empty_cache()
     be.set_option(dev, "reg_wires", 4)
+    be.set_option(dev, "read_map", 0)
 
 
 if __name__ == "__main__":
