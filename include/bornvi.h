@@ -134,6 +134,27 @@ int bornvi_paramshift_grad(bornvi_handle h, int ansatz, int n, int layers,
                            double* grad, void* workspace, size_t workspace_bytes,
                            bornvi_stream stream);
 
+/* ---- parameter-shift gradient with the dot product FUSED into the last circuit pass (replaces, like
+ * bornvi_paramshift_grad, the backward of ksd_vi_quantum.py:150 through diff_method="parameter-shift",
+ * quantum_born_machine.py:58): the shifted circuits' probabilities are never written; their last pass accumulates
+ * sum_z w_z q(z) per circuit instead (fixed summation order: deterministic).  Two calls around the caller's contraction:
+ *   begin : all passes but the last for the base circuit and the 2 p_count shifted ones (parameters p_begin,
+ *           p_begin + p_stride, ...), then the base circuit's last pass -> q_out dev [2^n];
+ *   (the caller computes y = K_p q, ksd2 = q.y -- any bornvi_stein_* contraction, all-reduced over the ranks)
+ *   finish: the shifted circuits' last pass with w = y -> grad dev [p_count]:
+ *           grad_p = s * sum_z w_z (q+_p(z) - q-_p(z)),  s = 1/2 if ksd2 == NULL, else 1/2 / sqrt(max(*ksd2, 1e-12)) with the
+ *           clamp's zero gradient below 1e-12 (ksd_vi_quantum.py:145); loss_out (or NULL) = sqrt(max(*ksd2, 1e-12)).
+ * The SAME workspace (bornvi_paramshift_dot_workspace_bytes, 16-byte aligned) must be passed to both and left alone in
+ * between.  Available for multi-pass plans of the 8-amplitude kernel ("reg_wires" = 3) without prefix sharing: the size
+ * query returns 0 otherwise (use bornvi_paramshift_probs + bornvi_ksd_grad_finish then). */
+size_t bornvi_paramshift_dot_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers, int p_count);
+int bornvi_paramshift_dot_begin(bornvi_handle h, int ansatz, int n, int layers, const double* theta, int p_begin,
+                                int p_count, int p_stride, double* q_out, void* workspace, size_t workspace_bytes,
+                                bornvi_stream stream);
+int bornvi_paramshift_dot_finish(bornvi_handle h, int ansatz, int n, int layers, int p_count, const double* w,
+                                 const double* ksd2, double* grad, double* loss_out, void* workspace,
+                                 size_t workspace_bytes, bornvi_stream stream);
+
 /* ---- un-fused gate application on a batch of statevectors (the gate-apply micro-benchmark of
  * BASELINE.json; one HBM round trip per gate = 32 * 2^n bytes per state).
  * state dev [batch, 2^n] complex128 (re, im interleaved), updated in place.

@@ -52,6 +52,11 @@ _PROTOS = {
     "bornvi_paramshift_grad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bornvi_paramshift_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_paramshift_dot_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bornvi_paramshift_dot_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bornvi_paramshift_dot_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bornvi_gate1q_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p]),
     "bornvi_cnot_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

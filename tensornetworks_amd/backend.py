@@ -223,6 +223,51 @@ def paramshift_probs(ansatz_type, n, layers, theta, p_begin, p_end, include_base
     return out
 
 
+def paramshift_dot_supported(ansatz_type, n, layers, dev, count):
+    """True when the fused path exists for this plan (multi-pass plan of the 8-amplitude kernel, no prefix sharing)."""
+    h = _ext.handle_for(dev)
+    key = (id(h), "dot_supported", ansatz_id(ansatz_type), int(n), int(layers), int(count))
+    if key not in _size_cache:       # (a size of 0 is the library's "not available": no error)
+        _size_cache[key] = int(_ext.lib().bornvi_paramshift_dot_workspace_bytes(h.h, ansatz_id(ansatz_type), int(n), int(layers), int(count)))
+    return _size_cache[key] > 0
+
+
+def paramshift_dot_begin(ansatz_type, n, layers, theta, p_begin, p_end, p_stride=1, ws_tag="dot"):
+    """First half of a parameter-shift step with the dot product fused into the last circuit pass: runs the base circuit
+    and the shifted circuits of p = p_begin, p_begin + p_stride, ... < p_end up to their last pass, and the base circuit
+    to the end.  Returns (q [2^n], token); give the token to paramshift_dot_finish once y = K_p q is known."""
+    dev = theta.device
+    h = _ext.handle_for(dev)
+    aid = ansatz_id(ansatz_type)
+    _chk_n(n)
+    _chk(theta, torch.float64, dev, "theta", num_params(ansatz_type, n, layers))
+    count = len(range(p_begin, p_end, p_stride))
+    need = int(_cached_size(h, "bornvi_paramshift_dot_workspace_bytes", aid, n, layers, count))
+    if need == 0:
+        raise BornviError("the fused parameter-shift dot is not available for this plan (see paramshift_dot_supported)")
+    ws = _ws(dev, need, ws_tag)
+    q = torch.empty(1 << n, dtype=torch.float64, device=dev)
+    h.call("bornvi_paramshift_dot_begin", aid, n, layers, _ptr(theta), int(p_begin), int(count), int(p_stride), _ptr(q), _ptr(ws),
+           ws.numel(), _ext.stream_ptr(dev))
+    return q, (aid, int(n), int(layers), count, ws)
+
+
+def paramshift_dot_finish(token, w, ksd2=None):
+    """Second half: the shifted circuits' last pass with the weights w [2^n] -> (loss [1] or None, grad [count]);
+    ksd2 [1] given: grad carries the factor 1 / (2 sqrt(max(ksd2, 1e-12))) and loss = sqrt(max(ksd2, 1e-12)); else 1/2."""
+    aid, n, layers, count, ws = token
+    dev = w.device
+    h = _ext.handle_for(dev)
+    _chk(w, torch.float64, dev, "w", 1 << n)
+    if ksd2 is not None:
+        _chk(ksd2, torch.float64, dev, "ksd2", 1)
+    grad = torch.empty(count, dtype=torch.float64, device=dev)
+    loss = torch.empty(1, dtype=torch.float64, device=dev) if ksd2 is not None else None
+    h.call("bornvi_paramshift_dot_finish", aid, n, layers, count, _ptr(w), _ptr(ksd2) if ksd2 is not None else None,
+           _ptr(grad) if count else None, _ptr(loss) if loss is not None else None, _ptr(ws), ws.numel(), _ext.stream_ptr(dev))
+    return loss, grad
+
+
 def paramshift_grad(ansatz_type, n, layers, theta, dLdq, p_begin, p_end, p_stride=1):
     """grad[i] = 1/2 dLdq . (q(theta + pi/2 e_p) - q(theta - pi/2 e_p)) for p = p_begin + i p_stride < p_end, float64."""
     dev = theta.device

@@ -217,12 +217,17 @@ size_t per_circuit_bytes(const Plan& p) {
 // bufA/bufB: ping-pong buffers; final_state / final_probs: destination of the last pass.
 // share (fast path only): see DevPlan::ShareChunk -- pass i runs circuits [0, active[i]), those from fresh[i] on
 // read slot 0 (the base circuit) of the input buffer; the last pass writes row d_tab[bc + b] of final_probs.
+// pass_begin / pass_end: the passes to run (default: all); `in0` is then the input of pass `pass_begin` (the ping-pong
+// continues from there: pass_input_buffer).  wdot / partials (8-amplitude kernel, last pass only): the fused dot product
+// with dL/dq instead of the probabilities (kernels_circuit8.hip).
 int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA, void* bufB, void* final_state,
                double* final_probs, const double* gates, long long gate_stride, hipStream_t st,
-               const DevPlan::ShareChunk* share = nullptr, double* trash = nullptr) {
+               const DevPlan::ShareChunk* share = nullptr, double* trash = nullptr, int pass_begin = 0, int pass_end = -1,
+               const double* wdot = nullptr, double* partials = nullptr) {
   const Plan& p = dp->plan;
   const void* in = in0;
-  for (int i = 0; i < p.n_passes; ++i) {
+  if (pass_end < 0) pass_end = p.n_passes;
+  for (int i = pass_begin; i < pass_end; ++i) {
     const bool last = (i == p.n_passes - 1);
     void* out = last ? final_state : ((in == bufA) ? bufB : bufA);
     if (dp->d_compact) {
@@ -240,8 +245,8 @@ int run_passes(bornvi_handle h, DevPlan* dp, int bc, const void* in0, void* bufA
                                        out, final_probs, gates, gate_stride, wgs,
                                        (((h->direct_stages >> 2) && (h->direct_stages >> 2) - 1 != i) ? 0 : (h->direct_stages & 3)) |
                                            ((h->alternate_walk && (i & 1)) ? 4 : 0) |
-                                           ((in0 == nullptr && h->direct_stages == 3 && h->zero_support) ? 8 : 0),
-                                       ps, st));
+                                           ((pass_begin == 0 && in0 == nullptr && h->direct_stages == 3 && h->zero_support) ? 8 : 0),
+                                       ps, last ? wdot : nullptr, last ? partials : nullptr, st));
     } else if (dp->d_fast && h->fast_path && dp->fast_workgroups > 0) {
       const int cus = h->circuit_cus > 0 ? h->circuit_cus : h->num_cus;
       const int wgs = h->fast_wgs_per_cu > 0 ? h->fast_wgs_per_cu * cus : dp->fast_workgroups / h->num_cus * cus;
@@ -492,7 +497,7 @@ int bornvi_create(int device_ordinal, bornvi_handle* out) {
   h->device = device_ordinal;
   // (A/B switches for whole test / bench runs; bornvi_set_option "reg_wires" / "read_map" are the per-handle form)
   if (const char* e = std::getenv("BORNVI_REG_WIRES")) { if (e[0] == '3' || e[0] == '4') h->opt.r = e[0] - '0'; }
-  if (const char* e = std::getenv("BORNVI_READ_MAP")) h->opt.read_map = e[0] == '1';
+  if (const char* e = std::getenv("BORNVI_READ_MAP")) h->opt.read_map = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
     h->num_cus = prop.multiProcessorCount;
@@ -539,7 +544,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   else if (!std::strcmp(name, "tile_bits_multi")) o.kmulti = (int)value;
   else if (!std::strcmp(name, "low_bits")) o.lo = (int)value;
   else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
-  else if (!std::strcmp(name, "read_map")) o.read_map = value != 0;
+  else if (!std::strcmp(name, "read_map")) o.read_map = value < 0 ? -1 : (value != 0 ? 1 : 0);   // -1: by the kernel (on with reg_wires = 3)
   else if (!std::strcmp(name, "reg_wires")) o.r = (int)value;
   else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
   if (o.kmax < 4 || o.kmax > 13 || (o.kmulti != 0 && (o.kmulti < 4 || o.kmulti > 13)) || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 1024 ||
@@ -554,7 +559,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
 int bornvi_get_option(bornvi_handle h, const char* name, long long* value) {
   if (!h || !name || !value) return BORNVI_ERR_INVALID;
   if (!std::strcmp(name, "reg_wires")) *value = h->opt.r;
-  else if (!std::strcmp(name, "read_map")) *value = h->opt.read_map ? 1 : 0;
+  else if (!std::strcmp(name, "read_map")) *value = h->opt.read_map;
   else if (!std::strcmp(name, "tile_bits")) *value = h->opt.kmax;
   else if (!std::strcmp(name, "tile_bits_multi")) *value = h->opt.kmulti;
   else if (!std::strcmp(name, "low_bits")) *value = h->opt.lo;
@@ -682,6 +687,98 @@ int bornvi_paramshift_grad(bornvi_handle h, int ansatz, int n, int layers, const
                                    (char*)workspace + probs_bytes, workspace_bytes - probs_bytes, stream);
   if (rc) return rc;
   HIPCHK(h, launch_shift_dot(shifted, ns, dLdq, nullptr, n, grad, nullptr, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
+// ---- parameter-shift gradient with the dot product fused into the last circuit pass ------------------------------
+namespace {
+struct DotLayout { size_t gates_bytes, state_bytes, partial_bytes, total; long long bc; };
+// workspace of a fused step: [gates | stateA | stateB | partials], all for 1 + 2 p_count circuits at once (no chunks)
+bool dot_layout(const Plan& p, int n, int p_count, DotLayout& L) {
+  L.bc = 1 + 2ll * p_count;
+  if (L.bc > 65535) return false;
+  L.gates_bytes = align_up((size_t)L.bc * gate_slots(p) * 64, 256);
+  L.state_bytes = align_up((size_t)L.bc * ((size_t)16 << n), 256);
+  L.partial_bytes = align_up((size_t)2 * p_count * ((size_t)8 << (n - p.k)), 256);
+  L.total = 512 + L.gates_bytes + 2 * L.state_bytes + L.partial_bytes;
+  return true;
+}
+// the fused path exists for multi-pass plans of the 8-amplitude kernel, without prefix sharing
+bool dot_supported(bornvi_handle h, DevPlan* dp) {
+  return dp->d_compact && dp->plan.n_passes >= 2 && !h->prefix_share && h->grad_engine == 0;
+}
+// input buffer of pass i when pass 0 starts from |0..0> and writes bufA first
+void* pass_input_buffer(int i, void* bufA, void* bufB) { return i == 0 ? nullptr : ((i & 1) ? bufA : bufB); }
+}  // namespace
+
+size_t bornvi_paramshift_dot_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers, int p_count) {
+  if (!h || p_count < 0) return 0;
+  DevPlan* dp = nullptr;
+  if (get_plan(h, ansatz, n, layers, &dp)) return 0;
+  DotLayout L;
+  if (!dot_supported(h, dp) || !dot_layout(dp->plan, n, p_count, L)) return 0;
+  return L.total;
+}
+
+int bornvi_paramshift_dot_begin(bornvi_handle h, int ansatz, int n, int layers, const double* theta, int p_begin, int p_count,
+                                int p_stride, double* q_out, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!theta || !q_out) return fail(h, BORNVI_ERR_INVALID, "null pointer");
+  const int P = num_params(ansatz, n, layers);
+  if (P < 0 || p_begin < 0 || p_count < 0 || p_stride < 1 || (p_count > 0 && (long long)p_begin + (long long)(p_count - 1) * p_stride >= P))
+    return fail(h, BORNVI_ERR_INVALID, "parameter range out of bounds");
+  DevPlan* dp = nullptr;
+  int rc = get_plan(h, ansatz, n, layers, &dp);
+  if (rc) return rc;
+  DotLayout L;
+  if (!dot_supported(h, dp) || !dot_layout(dp->plan, n, p_count, L))
+    return fail(h, BORNVI_ERR_UNSUPPORTED, "the fused parameter-shift dot needs a multi-pass plan of the 8-amplitude kernel (reg_wires = 3), no prefix sharing");
+  if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 15)) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or misaligned");
+  const Plan& p = dp->plan;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  double* gates = (double*)base;
+  void* bufA = base + L.gates_bytes;
+  void* bufB = base + L.gates_bytes + L.state_bytes;
+  DEVICE_SCOPE(h);
+  // circuit 0 = the base circuit, then (+p, -p) for the p_count parameters p_begin, p_begin + p_stride, ...
+  HIPCHK(h, launch_build_gates(dp->d_words, p.n_fused, theta, p.n_params, 1, p_begin, p_stride, 1, 0, (int)L.bc, gates, nullptr, gate_slots(p), 1, st));
+  rc = run_passes(h, dp, (int)L.bc, nullptr, bufA, bufB, nullptr, nullptr, gates, (long long)gate_slots(p) * 8, st, nullptr, nullptr, 0, p.n_passes - 1);
+  if (rc) return rc;
+  // the base circuit's last pass alone: q
+  void* in_last = pass_input_buffer(p.n_passes - 1, bufA, bufB);
+  return run_passes(h, dp, 1, in_last, bufA, bufB, nullptr, q_out, gates, (long long)gate_slots(p) * 8, st, nullptr, nullptr, p.n_passes - 1, p.n_passes);
+}
+
+int bornvi_paramshift_dot_finish(bornvi_handle h, int ansatz, int n, int layers, int p_count, const double* w, const double* ksd2,
+                                 double* grad, double* loss_out, void* workspace, size_t workspace_bytes, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (!w || p_count < 0 || (p_count > 0 && !grad)) return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  DevPlan* dp = nullptr;
+  int rc = get_plan(h, ansatz, n, layers, &dp);
+  if (rc) return rc;
+  DotLayout L;
+  if (!dot_supported(h, dp) || !dot_layout(dp->plan, n, p_count, L))
+    return fail(h, BORNVI_ERR_UNSUPPORTED, "the fused parameter-shift dot needs a multi-pass plan of the 8-amplitude kernel (reg_wires = 3), no prefix sharing");
+  if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 15)) return fail(h, BORNVI_ERR_WORKSPACE, "workspace too small or misaligned");
+  const Plan& p = dp->plan;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  double* gates = (double*)base;
+  char* bufA = base + L.gates_bytes;
+  char* bufB = base + L.gates_bytes + L.state_bytes;
+  double* partials = (double*)(base + L.gates_bytes + 2 * L.state_bytes);
+  DEVICE_SCOPE(h);
+  if (p_count > 0) {
+    // the shifted circuits' last pass (circuits 1 .. 2 p_count of the batch bornvi_paramshift_dot_begin left in the
+    // workspace): no probabilities, per-(circuit, tile) shares of  sum_z w_z q(z)
+    const size_t one_state = (size_t)16 << n;
+    char* in_last = (char*)pass_input_buffer(p.n_passes - 1, bufA, bufB) + one_state;
+    rc = run_passes(h, dp, 2 * p_count, in_last, bufA + one_state, bufB + one_state, nullptr, nullptr, gates + (size_t)gate_slots(p) * 8,
+                    (long long)gate_slots(p) * 8, st, nullptr, nullptr, p.n_passes - 1, p.n_passes, w, partials);
+    if (rc) return rc;
+  }
+  HIPCHK(h, launch_dot_finish(partials, p_count, 1ll << (n - p.k), ksd2, grad, loss_out, st));
   return BORNVI_OK;
 }
 
@@ -1035,7 +1132,7 @@ int bornvi_debug_circuit_stamps(bornvi_handle h, unsigned long long* out16) {
 
 long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words) {
   PlanOptions opt;
-  opt.read_map = (tile_bits & 0x100) != 0;       // (bit 8 of tile_bits: the planner's read_map option)
+  opt.read_map = (tile_bits & 0x100) ? 1 : 0;    // (bit 8 of tile_bits: the planner's read_map option)
   opt.r = (tile_bits & 0x200) ? 3 : 4;           // (bit 9: 3 register wires, the plan circuit_pass_r3_kernel runs)
   if (opt.r == 4) opt.max_threads = 512;
   tile_bits &= 0xff;
@@ -1054,6 +1151,7 @@ long long bornvi_plan_describe(int ansatz, int n, int layers, int tile_bits, uin
 int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, int* out, int cap) {
   PlanOptions opt;
   opt.r = (tile_bits & 0x200) ? 3 : 4;
+  opt.read_map = (tile_bits & 0x100) ? 1 : 0;
   if (opt.r == 4) opt.max_threads = 512;
   tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }
@@ -1068,7 +1166,7 @@ int bornvi_plan_param_first_pass(int ansatz, int n, int layers, int tile_bits, i
 long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words,
                                     uint32_t* pass_off_out, int cap_passes) {
   PlanOptions opt;
-  opt.read_map = (tile_bits & 0x100) != 0;
+  opt.read_map = (tile_bits & 0x100) ? 1 : 0;
   opt.r = (tile_bits & 0x200) ? 3 : 4;
   if (opt.r == 4) opt.max_threads = 512;
   tile_bits &= 0xff;
@@ -1093,7 +1191,7 @@ long long bornvi_plan_fast_describe(int ansatz, int n, int layers, int tile_bits
 long long bornvi_plan_compact_describe(int ansatz, int n, int layers, int tile_bits, uint32_t* out, size_t cap_words,
                                        uint32_t* pass_off_out, int cap_passes) {
   PlanOptions opt;
-  opt.read_map = (tile_bits & 0x100) != 0;
+  opt.read_map = (tile_bits & 0x100) ? 1 : 0;
   opt.r = 3;
   tile_bits &= 0xff;
   if (tile_bits > 0) { opt.kmax = tile_bits; opt.kmulti = tile_bits; }

@@ -26,6 +26,9 @@ RESOURCE_BUDGET = {
     "quadform_kernel": (0, 0),
     "gram_mfma_kernel": (0, 0),
     "circuit_pass_fast_kernelILb0": (20, 0),      # (20 bytes: spilled SGPRs of the set-up code, outside the tile loop)
+    "circuit_pass_r3_kernelILb0": (0, 0),         # 8 amplitudes per thread: <= 128 VGPRs (four waves per SIMD) without scratch
+    "circuit_pass_r3_kernelILb1": (24, 4),        # its fused-dot instantiation (last pass only): 8 weights more per thread; the few
+                                                  # spilled address words are reloaded at the end of a trip, not inside the stages
 }
 
 

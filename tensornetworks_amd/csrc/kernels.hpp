@@ -40,7 +40,11 @@ int circuit_r3_workgroups_per_cu(int threads, size_t lds);
 hipError_t launch_circuit_pass_r3(const uint32_t* plan, uint32_t pass_off, const uint32_t* ctab, uint32_t ct_off, int n, int k,
                                   size_t lds, int batch, const void* in, void* out, double* probs, const double* gates,
                                   long long gate_stride, int max_workgroups, int direct_mask, const PrefixShare& share,
-                                  hipStream_t st);
+                                  const double* wdot, double* partials, hipStream_t st);
+// grad[p] = s * (sum_g partials[(2p) * tiles + g] - sum_g partials[(2p + 1) * tiles + g]),  s = 1/2 (ksd2 == null) or
+// 1/2 / sqrt(max(ksd2, 1e-12)) with the clamp's zero gradient below 1e-12; loss_out (or null) = sqrt(max(ksd2, 1e-12))
+hipError_t launch_dot_finish(const double* partials, int n_shift, long long tiles, const double* ksd2, double* grad,
+                             double* loss_out, hipStream_t st);
 hipError_t launch_gate1q(double* state, int n, long long batch, int wire, const double* U, hipStream_t st);
 hipError_t launch_cnot(double* state, int n, long long batch, int control, int target, hipStream_t st);
 hipError_t launch_born_probs(const double* state, double* probs, int n, long long batch, hipStream_t st);

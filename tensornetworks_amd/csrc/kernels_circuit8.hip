@@ -145,10 +145,14 @@ __device__ __forceinline__ void gate8_last(double (&ar)[8], double (&ai)[8], con
 // One stage on the 8 amplitudes a thread owns; NG fused gates on register bits 0 .. NG-1, optional CZ sign products.
 // IO: 0 = LDS -> LDS; 1 = the amplitudes are the prefetched registers `v` (first stage of a pass, results to LDS);
 // 2 = LDS -> HBM (last stage of a pass).
-template <int NG, bool PRE, bool POST, int IO, bool FIN>
+// DOT (last stage of the final pass, IO == 2 and FIN): no probabilities are stored; acc += sum_j |z_j|^2 * W[slot j's outcome]
+// instead -- the parameter-shift dot product with dL/dq fused into the pass (W: the thread's 8 weights, loaded once per
+// tile row; a gate's exchange flag permutes which weight a register slot meets: one of eight straight-line variants).
+template <int NG, bool PRE, bool POST, int IO, bool FIN, bool DOT = false>
 __device__ __forceinline__ void stage8(char* __restrict__ lds, const char* __restrict__ gb, const uint32_t (&MAT)[3], uint32_t my_rw,
                                        uint32_t my_sg, const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8], uint32_t hbm_off,
-                                       const uint32_t (&hb)[3], void* hbm_base, bool cross, double scale) {
+                                       const uint32_t (&hb)[3], void* hbm_base, bool cross, double scale, const double (&W)[8],
+                                       double& acc) {
   double ar[8], ai[8];
   // all matrices of the stage are requested before the amplitudes (scalar loads return out of order with LDS reads: one
   // lgkmcnt(0) in front of the first gate covers both)
@@ -197,6 +201,18 @@ __device__ __forceinline__ void stage8(char* __restrict__ lds, const char* __res
     if (sig & 2u) post_bits = ((post_bits & 0x33u) << 2) | ((post_bits >> 2) & 0x33u);
     if (sig & 4u) post_bits = ((post_bits & 0x0fu) << 4) | ((post_bits >> 4) & 0x0fu);
   }
+  if (DOT) {
+    if (NG > 0) gate8<(NG > 0 ? NG - 1 : 0)>(ar, ai, NG == 2 ? Ub : Ua);
+    double a = acc;
+    switch (sig) {      // register slot j holds the amplitude of outcome slot j ^ sig
+#define BORNVI_DOT8(S_) case S_: _Pragma("unroll") for (int j = 0; j < 8; ++j) a = fma(fma(ar[j], ar[j], ai[j] * ai[j]), W[j ^ S_], a); break;
+      BORNVI_DOT8(0) BORNVI_DOT8(1) BORNVI_DOT8(2) BORNVI_DOT8(3) BORNVI_DOT8(4) BORNVI_DOT8(5) BORNVI_DOT8(6) BORNVI_DOT8(7)
+#undef BORNVI_DOT8
+      default: break;
+    }
+    acc = a;
+    return;
+  }
   if (NG > 0) wa0 ^= (IO == 2) ? comb3_rt(sig, hb) : comb3_rt(sig, WB);
   if (NG > 0) {
     asm volatile("" : "+v"(wa0));     // the write base is formed here, before the last gate
@@ -212,12 +228,13 @@ __device__ __forceinline__ void stage8(char* __restrict__ lds, const char* __res
   }
 }
 
-template <int IO, bool FIN>
+template <int IO, bool FIN, bool DOT = false>
 __device__ __forceinline__ void dispatch8(uint32_t kind, char* __restrict__ lds, const char* __restrict__ gb, const uint32_t (&MAT)[3],
                                           uint32_t my_rw, uint32_t my_sg, const uint32_t (&RB)[3], const uint32_t (&WB)[3], d2_t (&v)[8],
-                                          uint32_t hbm_off, const uint32_t (&hb)[3], void* hbm_base, bool cross, double scale) {
+                                          uint32_t hbm_off, const uint32_t (&hb)[3], void* hbm_base, bool cross, double scale,
+                                          const double (&W)[8], double& acc) {
 #define BORNVI_ST8(NG, PRE, POST) \
-  case (NG) | ((PRE) << 3) | ((POST) << 4): stage8<NG, PRE, POST, IO, FIN>(lds, gb, MAT, my_rw, my_sg, RB, WB, v, hbm_off, hb, hbm_base, cross, scale); break;
+  case (NG) | ((PRE) << 3) | ((POST) << 4): stage8<NG, PRE, POST, IO, FIN, DOT>(lds, gb, MAT, my_rw, my_sg, RB, WB, v, hbm_off, hb, hbm_base, cross, scale, W, acc); break;
 #define BORNVI_ST8_NG(PRE, POST) BORNVI_ST8(0, PRE, POST) BORNVI_ST8(1, PRE, POST) BORNVI_ST8(2, PRE, POST) BORNVI_ST8(3, PRE, POST)
 #if BORNVI_R3_NO_GATES
   kind &= ~7u;
@@ -235,11 +252,14 @@ __device__ __forceinline__ void dispatch8(uint32_t kind, char* __restrict__ lds,
 
 }  // namespace
 
+// DOT (final pass of a multi-pass plan only): instead of the probabilities of circuit b, partials[b * tiles + g] = the
+// tile's share of  sum_z wdot[z] q_b(z)  (fixed summation order: deterministic); probs is not written.
+template <bool DOT>
 __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     const uint32_t* __restrict__ plan, uint32_t pass_off, const uint32_t* __restrict__ ctab, uint32_t ct_off,
     const double2* __restrict__ in, double2* __restrict__ out, double* __restrict__ probs,
     const double* __restrict__ gates, long long gate_stride, long long state_stride, long long total_tiles,
-    int direct_mask, PrefixShare share) {
+    int direct_mask, PrefixShare share, const double* __restrict__ wdot, double* __restrict__ partials) {
   extern __shared__ double2 tile[];
   const uint32_t* __restrict__ P = plan + pass_off;
   const uint32_t* __restrict__ C = ctab + ct_off;
@@ -263,6 +283,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
   uint32_t* __restrict__ lane_tab = reinterpret_cast<uint32_t*>(tile + ksize);
   uint32_t* __restrict__ uni_tab = lane_tab + nrows * 64u;
   uint32_t* __restrict__ mask_tab = uni_tab + nrows * NW;
+  double* __restrict__ red_tab = reinterpret_cast<double*>(lane_tab + (((nrows * 64u + nrows * NW + (nsign ? nsign : 1u) * NW) + 1u) & ~1u));   // [NW] wave sums (DOT)
   // (direct_mask: bit 0 / 1 allow the direct first / last stage; bit 2: walk the tiles backwards; bit 3: support of |0..0>)
   const bool direct_in = (H[CH_DIRECT] & 1u) && !init && nstages > 0 && (direct_mask & 1);
   const bool direct_out = (H[CH_DIRECT] & 2u) && nstages > 1 && (direct_mask & 2);
@@ -284,6 +305,11 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
 #if BORNVI_R3_STAGGER
   for (uint32_t q = 0; q < ((blockIdx.x >> 3) & 3u) * (BORNVI_R3_STAGGER / 4); ++q) __builtin_amdgcn_s_sleep(1);
 #endif
+  double W[8];              // DOT: dL/dq at the thread's 8 outcomes of tile row g_w
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) W[j] = 0.0;
+  uint32_t g_w = 0xffffffffu;
   d2_t v[8];                // amplitudes of the NEXT tile (in flight during the current tile's stages)
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (d2_t){0.0, 0.0};
@@ -298,20 +324,22 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     const uint32_t RB_[3] = {CS_[CS_RB], CS_[CS_RB + 1], CS_[CS_RB + 2]};                                       \
     const uint32_t WB_[3] = {CS_[CS_WB], CS_[CS_WB + 1], CS_[CS_WB + 2]};                                       \
     const uint32_t MAT_[3] = {CS_[CS_MAT], CS_[CS_MAT + 1], CS_[CS_MAT + 2]};                                   \
-    const uint32_t rw_ = lane_tab[(uint32_t)(S_) * 64u + lane] ^ uni_tab[(uint32_t)(S_) * NW + wv];             \
+    const uint32_t rw_ = lane_tab[(uint32_t)(S_) * 64u + lane_t] ^ uni_tab[(uint32_t)(S_) * NW + wv_t];             \
     uint32_t sg_ = 0;                                                                                           \
     if (kind_ >> 3) {                                                                                           \
       const uint32_t sr_ = (uint32_t)__popc(sign_any & ((1u << (S_)) - 1u));                                    \
-      sg_ = lane_tab[((uint32_t)nstages + sr_) * 64u + lane] ^ uni_tab[((uint32_t)nstages + sr_) * NW + wv];    \
-      const uint32_t mk_ = mask_tab[sr_ * NW + wv];                                                             \
-      sg_ ^= (0u - ((uint32_t)__popc(lane & (mk_ & 0xffu)) & 1u)) & 0x0000ffffu;                                \
-      sg_ ^= (0u - ((uint32_t)__popc(lane & (mk_ >> 8)) & 1u)) & 0xffff0000u;                                   \
+      sg_ = lane_tab[((uint32_t)nstages + sr_) * 64u + lane_t] ^ uni_tab[((uint32_t)nstages + sr_) * NW + wv_t];    \
+      const uint32_t mk_ = mask_tab[sr_ * NW + wv_t];                                                             \
+      sg_ ^= (0u - ((uint32_t)__popc(lane_t & (mk_ & 0xffu)) & 1u)) & 0x0000ffffu;                                \
+      sg_ ^= (0u - ((uint32_t)__popc(lane_t & (mk_ >> 8)) & 1u)) & 0xffff0000u;                                   \
     }                                                                                                           \
-    const uint32_t ho_ = (IO_) == 2 ? (lane_tab[row_out_d * 64u + lane] ^ uni_tab[row_out_d * NW + wv]) : 0u;   \
-    if ((IO_) == 2 && fin)                                                                                      \
-      dispatch8<IO_, true>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, scale); \
+    const uint32_t ho_ = (IO_) == 2 ? (lane_tab[row_out_d * 64u + lane_t] ^ uni_tab[row_out_d * NW + wv_t]) : 0u;   \
+    if ((IO_) == 2 && fin && DOT)                                                                               \
+      dispatch8<IO_, true, DOT>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, scale, W, acc); \
+    else if ((IO_) == 2 && fin)                                                                                 \
+      dispatch8<IO_, true>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, scale, W, acc); \
     else                                                                                                        \
-      dispatch8<IO_, false>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, 1.0); \
+      dispatch8<IO_, false>(kind_, lds, gb, MAT_, rw_, sg_, RB_, WB_, v, ho_, out_step_d, hbm_base, CS_[CS_CROSS] != 0u, 1.0, W, acc); \
   } while (0)
 
   const long long walk_flip = total_tiles - 1;
@@ -324,6 +352,11 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
   for (long long Scur = (long long)blockIdx.x - (long long)gridDim.x;; Scur += gridDim.x) {
     const bool real = Scur >= 0;
     const long long Snext = Scur + gridDim.x;
+    // (per-trip copies of the lane / wave numbers the compiler cannot see through: nothing derived from them -- a dozen
+    // LDS addresses of table rows -- is hoisted out of the tile loop and kept in registers across the stages)
+    uint32_t lane_t = lane, wv_t = wv;
+    asm volatile("" : "+v"(lane_t), "+v"(wv_t));
+    const uint32_t t_t = (wv_t << 6) | lane_t;
     const bool has_next = Snext < total_tiles;
     long long Tcur, Tnext;
     if (zskip) {     // INIT pass: the one non-zero tile of every circuit first, spread over all workgroups, then the zero tiles
@@ -351,15 +384,24 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     }
     void* hbm_base = fin ? (void*)pdst : (void*)dst;
     if (real) {
-      // the tile has arrived in registers: all but this wave's 8 tile-out stores are done
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // the tile has arrived in registers: all but this wave's 8 tile-out stores are done (DOT: a trip issues no stores)
+      if (DOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (DOT && g != g_w) {      // the thread's 8 weights of this tile row (the grid keeps a workgroup on one row: once per launch)
+        g_w = g;
+        const uint32_t o_ = direct_out ? (lane_tab[row_out_d * 64u + lane_t] ^ uni_tab[row_out_d * NW + wv_t])
+                                       : (lane_tab[row_out_n * 64u + lane_t] ^ uni_tab[row_out_n * NW + wv_t]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) W[j] = wdot[(o_ ^ (direct_out ? comb3(j, out_step_d) : comb3(j, out_step_n))) >> 3];
+      }
+      acc = 0.0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i]));
       if (init) {
         if (!zero_tile)
-          for (uint32_t u = t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
+          for (uint32_t u = t_t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
       } else if (!direct_in) {
-        const uint32_t slot_t = (lane_tab[row_slot * 64u + lane] ^ uni_tab[row_slot * NW + wv]) & 0xffffu;
+        const uint32_t slot_t = (lane_tab[row_slot * 64u + lane_t] ^ uni_tab[row_slot * NW + wv_t]) & 0xffffu;
 #pragma unroll
         for (int i = 0; i < 8; ++i) tile[slot_t ^ comb3(i, fill_step)] = make_double2(v[i].x, v[i].y);
       }
@@ -370,7 +412,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     if (has_next) {
       const uint32_t gn_ = (uint32_t)(Tnext & ((1ll << gbits) - 1));
       const long long bn_ = Tnext >> gbits;
-      uint32_t tt_ = t;
+      uint32_t tt_ = t_t;
       asm volatile("" : "+v"(tt_));   // (nothing derived from the thread id is hoisted out of the loop)
       if (!init && gn_ != g_pref) {   // rare: compiler-tracked load, waited for inside this branch
         g_pref = gn_;
@@ -397,7 +439,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
       // ---- tile out: exactly 8 vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
       if (noop_tile) {
       } else if (zero_tile) {
-        const uint32_t off0 = (xor_cols16(t, kt, P + PW_OUT_COL) ^ xor_cols16(g, gbits, P + PW_OUT_GCOL)) << out_shift;
+        const uint32_t off0 = (xor_cols16(t_t, kt, P + PW_OUT_COL) ^ xor_cols16(g, gbits, P + PW_OUT_GCOL)) << out_shift;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const uint32_t off = off0 ^ comb3(i, out_step_n);
@@ -405,15 +447,29 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
           else async_store16(off, (d2_t){0.0, 0.0}, dst);
         }
       } else if (!direct_out) {
-        const uint32_t slot_t = (lane_tab[row_slot * 64u + lane] ^ uni_tab[row_slot * NW + wv]) >> 16;
-        const uint32_t off0 = lane_tab[row_out_n * 64u + lane] ^ uni_tab[row_out_n * NW + wv];
+        const uint32_t slot_t = (lane_tab[row_slot * 64u + lane_t] ^ uni_tab[row_slot * NW + wv_t]) >> 16;
+        const uint32_t off0 = lane_tab[row_out_n * 64u + lane_t] ^ uni_tab[row_out_n * NW + wv_t];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const double2 x = tile[slot_t ^ comb3(i, drain_step)];
           const uint32_t off = off0 ^ comb3(i, out_step_n);
-          if (fin) async_store8(off, (x.x * x.x + x.y * x.y) * scale, pdst);
+          if (DOT) acc = fma(x.x * x.x + x.y * x.y, W[i], acc);
+          else if (fin) async_store8(off, (x.x * x.x + x.y * x.y) * scale, pdst);
           else async_store16(off, (d2_t){x.x, x.y}, dst);
         }
+      }
+    }
+    if (DOT && real) {
+      // the tile's share of the dot product: wave shuffles, then the waves' sums in wave order (fixed: deterministic)
+      double a_ = acc;
+#pragma unroll
+      for (int off_ = 32; off_ > 0; off_ >>= 1) a_ += __shfl_xor(a_, off_, 64);
+      if (lane_t == 0) red_tab[wv_t] = a_;
+      __syncthreads();
+      if (t_t == 0) {
+        double tot_ = 0.0;
+        for (uint32_t w_ = 0; w_ < NW; ++w_) tot_ += red_tab[w_];
+        partials[((size_t)b << gbits) + g] = tot_ * scale;
       }
     }
     if (!has_next) break;
@@ -424,8 +480,8 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
       if (gnx != g_tab && !(zskip && gnx != 0u)) {
         g_tab = gnx;
         if (real) __syncthreads();            // (a slower wave may still be reading the rows of the current tile row)
-        for (uint32_t i = t; i < nrows * NW; i += T) uni_tab[i] = UNI[(size_t)gnx * nrows * NW + i];
-        for (uint32_t i = t; i < nsign * NW; i += T) mask_tab[i] = MASK[(size_t)gnx * nsign * NW + i];
+        for (uint32_t i = t_t; i < nrows * NW; i += T) uni_tab[i] = UNI[(size_t)gnx * nrows * NW + i];
+        for (uint32_t i = t_t; i < nsign * NW; i += T) mask_tab[i] = MASK[(size_t)gnx * nsign * NW + i];
       }
     }
     // (trip -1 issued no stores: the first real trip's vmcnt(8) would let its 8 loads pass -- wait for them here)
@@ -436,28 +492,64 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
 }
 
 hipError_t prepare_circuit_r3_kernel(size_t lds_bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_r3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_r3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(circuit_pass_r3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_bytes);
 }
 
 int circuit_r3_workgroups_per_cu(int threads, size_t lds) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_r3_kernel, threads, lds) != hipSuccess) return 0;
-  return nb;
+  int nb = 0, nd = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, circuit_pass_r3_kernel<false>, threads, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nd, circuit_pass_r3_kernel<true>, threads, lds) != hipSuccess) return 0;
+  return nb < nd ? nb : nd;
 }
 
 hipError_t launch_circuit_pass_r3(const uint32_t* plan, uint32_t pass_off, const uint32_t* ctab, uint32_t ct_off, int n, int k,
                                   size_t lds, int batch, const void* in, void* out, double* probs, const double* gates,
                                   long long gate_stride, int max_workgroups, int direct_mask, const PrefixShare& share,
-                                  hipStream_t st) {
+                                  const double* wdot, double* partials, hipStream_t st) {
   const long long total_tiles = (long long)batch << (n - k);
   if (total_tiles == 0) return hipSuccess;
   long long wgs = (max_workgroups > 0 && total_tiles > max_workgroups) ? max_workgroups : total_tiles;
   const long long per_state = 1ll << (n - k);
   if (wgs > per_state) wgs -= wgs % per_state;      // a workgroup keeps its tile row: its table rows stay in LDS
-  circuit_pass_r3_kernel<<<dim3((unsigned)wgs), dim3(1u << (k - 3)), lds, st>>>(
-      plan, pass_off, ctab, ct_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles,
-      direct_mask, share);
+  if (wdot)
+    circuit_pass_r3_kernel<true><<<dim3((unsigned)wgs), dim3(1u << (k - 3)), lds, st>>>(
+        plan, pass_off, ctab, ct_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles,
+        direct_mask, share, wdot, partials);
+  else
+    circuit_pass_r3_kernel<false><<<dim3((unsigned)wgs), dim3(1u << (k - 3)), lds, st>>>(
+        plan, pass_off, ctab, ct_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles,
+        direct_mask, share, nullptr, nullptr);
+  return hipGetLastError();
+}
+
+// ---- gradient from the fused-dot partials (one thread per parameter, tiles summed in order: deterministic) ----
+__global__ __launch_bounds__(64) void dot_finish_kernel(const double* __restrict__ partials, int n_shift, long long tiles,
+                                                        const double* __restrict__ ksd2, double* __restrict__ grad,
+                                                        double* __restrict__ loss_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double scale = 0.5, loss = 0.0;
+  if (ksd2) {
+    const double k2 = *ksd2;
+    loss = sqrt(k2 < 1e-12 ? 1e-12 : k2);
+    scale = (k2 < 1e-12) ? 0.0 : 0.5 / loss;
+  }
+  if (p == 0 && loss_out && ksd2) *loss_out = loss;
+  if (p >= n_shift) return;
+  const double* pp = partials + (2ll * p) * tiles;
+  const double* pm = pp + tiles;
+  double sp = 0.0, sm = 0.0;
+  for (long long g = 0; g < tiles; ++g) { sp += pp[g]; sm += pm[g]; }
+  grad[p] = scale * (sp - sm);
+}
+
+hipError_t launch_dot_finish(const double* partials, int n_shift, long long tiles, const double* ksd2, double* grad,
+                             double* loss_out, hipStream_t st) {
+  const int blocks = n_shift > 0 ? (n_shift + 63) / 64 : 1;
+  dot_finish_kernel<<<dim3((unsigned)blocks), dim3(64), 0, st>>>(partials, n_shift, tiles, ksd2, grad, loss_out);
   return hipGetLastError();
 }
 

@@ -500,8 +500,8 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     // thread index, not from the register wires).  At least 2^4 contiguous elements are kept (256-byte runs).
     {
       std::vector<int> f_cur, l_cur, f_nxt, l_nxt;
-      first_last_stage_targets(ops, P.ops, n, r, i == 0 && !spec.in_state, f_cur, l_cur, opt.read_map);
-      first_last_stage_targets(ops, passes[i + 1].ops, n, r, false, f_nxt, l_nxt, opt.read_map);
+      first_last_stage_targets(ops, P.ops, n, r, i == 0 && !spec.in_state, f_cur, l_cur, opt.use_read_map());
+      first_last_stage_targets(ops, passes[i + 1].ops, n, r, false, f_nxt, l_nxt, opt.use_read_map());
       std::vector<char> busy(n, 0);
       for (int w : l_cur) busy[w] = 1;
       for (int w : f_nxt) busy[w] = 1;
@@ -645,10 +645,10 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     //      the 2^r-element group a thread owns, so the in-place write-back needs no extra barrier.
     std::vector<int> pool = core, rest;
     uint32_t nstages = 0;
-    const bool defer_cx3 = pick_defer_policy(ops, core, n, r, opt.read_map);
+    const bool defer_cx3 = pick_defer_policy(ops, core, n, r, opt.use_read_map());
     while (!pool.empty()) {
       StageSel sel;
-      stage_select(ops, pool, n, r, sel, rest, defer_cx3, opt.read_map);
+      stage_select(ops, pool, n, r, sel, rest, defer_cx3, opt.use_read_map());
       if (sel.count() == 0) { msg = "stage planner made no progress"; return false; }
       if (getenv("BORNVI_PLAN_DEBUG")) {
         auto show = [&](const char* nm, const std::vector<int>& v) {

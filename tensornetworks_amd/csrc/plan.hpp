@@ -133,13 +133,18 @@ struct PlanOptions {
   int kmulti = 0;    // tile bits when the state needs several tiles (n > kmax).  0 = by measurement on MI355X
                      // (DESIGN.md 4.1): 2^13 (one 512-thread workgroup per CU, the large-tile instantiation of the
                      // fast kernel) wherever the fast kernel can run it, else 2^11 (make_plan)
-  int r = 4;         // register wires per stage: 4 = 2^4 amplitudes per thread (circuit_pass_fast_kernel, <= 256 VGPRs, two waves
-                     // per SIMD), 3 = 2^3 per thread (circuit_pass_r3_kernel: <= 128 VGPRs, four waves per SIMD, a third more stages)
+  int r = 3;         // register wires per stage: 3 = 2^3 amplitudes per thread (circuit_pass_r3_kernel: <= 128 VGPRs, four waves per
+                     // SIMD; the default: faster than or level with the other for every n measured), 4 = 2^4 per
+                     // thread (circuit_pass_fast_kernel, <= 256 VGPRs, two waves per SIMD; also the fallback where a plan is not
+                     // eligible for the first)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 1024;
-  bool read_map = false;   // phase-0 CNOTs may target thread-held wires (general GF(2) read map, STAGE_CROSS_READ): fewer
-                           // stages, but such a stage needs a barrier between its reads and its write-back, which costs more than
-                           // the stages saved (MI355X, n = 16 / 20: +3.7 % / +2.8 %): off; kept for A/B (option "read_map")
+  int read_map = -1;       // phase-0 CNOTs may target thread-held wires (general GF(2) read map, STAGE_CROSS_READ): fewer stages,
+                           // but such a stage needs a barrier between its reads and its write-back.  Measured on the MI355X
+                           // (n = 16 / 20): with 16 amplitudes per thread (8 waves in step per CU) the barrier costs more than
+                           // the stages saved (+3.7 % / +2.8 %); with 8 per thread (16 waves) it pays (-2.6 % / -5.7 %: 44 -> 37
+                           // and 70 -> 58 stages).  -1 = by that measurement (on iff r == 3), 0 / 1 = forced (option "read_map")
+  bool use_read_map() const { return read_map < 0 ? r == 3 : read_map != 0; }
 };
 
 struct Plan {
@@ -242,10 +247,10 @@ struct CompactTables {
   std::vector<uint32_t> words;
   std::vector<uint32_t> pass_off;
   int max_rows = 0, max_sign = 0, max_stages = 0;
-  // LDS of circuit_pass_r3_kernel: tile | LANE | UNI (one tile row) | MASK
+  // LDS of circuit_pass_r3_kernel: tile | LANE | UNI (one tile row) | MASK | wave sums
   size_t lds_bytes(int k) const {
     const size_t nw = ((size_t)1 << (k - 3)) / 64;
-    return ((size_t)16 << k) + (size_t)max_rows * 64 * 4 + (size_t)max_rows * nw * 4 + (size_t)(max_sign > 0 ? max_sign : 1) * nw * 4 + 64;
+    return ((size_t)16 << k) + (size_t)max_rows * 64 * 4 + (size_t)max_rows * nw * 4 + (size_t)(max_sign > 0 ? max_sign : 1) * nw * 4 + 8 + nw * 8 + 64;   // (+ the waves' partial sums of the fused dot)
   }
 };
 // false (with msg) when the plan is not eligible (r != 3, tiles below 2^9, more matrix pieces than threads) or when a table

@@ -137,6 +137,11 @@ class KSDVariationalInference:
         # one forward and one backward walk over the gates (bornvi_adjoint_state / _vjp) -- the same gradient to
         # rounding from about three circuit evaluations; every rank computes it whole (nothing to shard).
         self.grad_engine = "paramshift"
+        # The parameter-shift dot product  sum_z dL/dq_z (q+ - q-)(z)  inside the shifted circuits' last pass instead of a
+        # pass over their stored probabilities (bornvi_paramshift_dot_begin / _finish): still all 2P circuit evaluations,
+        # same gradient to rounding; taken where the library offers it (multi-pass plans of the 8-amplitude kernel),
+        # else the probabilities are written and dotted as before.  False: always the un-fused path (A/B).
+        self.fused_dot = True
         # A dense K_p >= 1 GiB is placed by measurement: up to this many copies are built (each in fresh memory while the
         # earlier ones are held), the contraction is timed on each, the fastest stays (_place_gram).  The contraction's
         # rate depends on where the driver put K_p RELATIVE to the workspace its partial sums go to -- 2.55 or 2.78 ms
@@ -437,6 +442,19 @@ class KSDVariationalInference:
                 tns.record_stream(main)
             theta64.record_stream(sa)
             theta64.record_stream(sc)
+        elif not overlap and self.fused_dot and backend.paramshift_dot_supported(at, n, L, dev, n_local):
+            # The dot product with dL/dq fused into the shifted circuits' last pass (kernels_circuit8.hip): base circuit
+            # and all but the last pass of the shifted ones -> q -> contraction -> last pass of the shifted circuits with
+            # w = y.  Their probabilities are never written or re-read (8 GB each way at n = 20).
+            with self._timed("circuits"):
+                q, token = backend.paramshift_dot_begin(at, n, L, theta64, lo, hi, p_stride=step)
+            with self._timed("stein"):
+                ksd2, y = self._stein_contract(q)
+            with self._timed("finish"):
+                loss, grad_local = backend.paramshift_dot_finish(token, y, ksd2)
+                with self._timed("allgather"):
+                    grad = shard.all_gather_grad(grad_local, P, self.process_group)
+            return loss, grad, q
         elif not overlap:
             with self._timed("circuits"):
                 probs = backend.paramshift_probs(at, n, L, theta64, lo, hi, include_base=True, p_stride=step)

@@ -22,8 +22,12 @@ int main(int argc, char** argv) {
   // argv: quadruples "ansatz n layers tile_bits" (ansatz -1 = Kronecker mat-vec plan)
   for (int i = 1; i + 3 < argc; i += 4) {
     const int ansatz = atoi(argv[i]), n = atoi(argv[i + 1]), L = atoi(argv[i + 2]), kb = atoi(argv[i + 3]);
+    // (kb as the library's describe functions take it: bits 0-7 tile bits, bit 8 read map, bit 9 the 3-register-wire plan)
     bornvi::PlanOptions opt;
-    if (kb > 0) { opt.kmax = kb; opt.kmulti = kb; }
+    opt.read_map = (kb & 0x100) ? 1 : 0;
+    opt.r = (kb & 0x200) ? 3 : 4;
+    if (opt.r == 4) opt.max_threads = 512;
+    if ((kb & 0xff) > 0) { opt.kmax = kb & 0xff; opt.kmulti = kb & 0xff; }
     bornvi::Plan p;
     std::string msg;
     const bool ok = ansatz == -1 ? bornvi::make_kron_plan(n, opt, p, msg) : bornvi::make_plan(ansatz, n, L, opt, p, msg);
@@ -37,9 +41,14 @@ int main(int argc, char** argv) {
         for (uint32_t s = 0; s < F[bornvi::FH_NSTAGES]; ++s)
           kinds_ok = kinds_ok && bornvi::fast_stage_kind_supported(F[bornvi::FH_WORDS + s * bornvi::FS_WORDS + bornvi::FS_KIND]);
       }
-    printf("%d %d %d %d plan %zu %016llx fast %zu %016llx kinds %d\n", ansatz, n, L, kb, p.words.size(),
+    // the compact tables of the 8-amplitude kernel (every word checked against its point evaluation by the builder)
+    bornvi::CompactTables ct;
+    std::string cmsg;
+    const bool compact = p.r == 3 && bornvi::build_compact_tables(p, ct, cmsg) && ct.lds_bytes(p.k) <= bornvi::MAX_LDS_BYTES;
+    printf("%d %d %d %d plan %zu %016llx fast %zu %016llx kinds %d compact %zu %016llx\n", ansatz, n, L, kb, p.words.size(),
            (unsigned long long)fnv(p.words), fast ? ft.words.size() : (size_t)0,
-           (unsigned long long)(fast ? fnv(ft.words) : 0ull), kinds_ok ? 1 : 0);
+           (unsigned long long)(fast ? fnv(ft.words) : 0ull), kinds_ok ? 1 : 0, compact ? ct.words.size() : (size_t)0,
+           (unsigned long long)(compact ? fnv(ct.words) : 0ull));
   }
   return 0;
 }

@@ -118,7 +118,7 @@ def rccl_single_rank(rank, world_size, port, out_dir):
         raise
 
 
-def cold_batch(rank, world_size, port, n, L, read_map, out_dir):
+def cold_batch(rank, world_size, port, n, L, read_map, out_dir, reg_wires=3):
     """A FRESH process runs one full parameter-shift batch and checks every row's sum: the first launches of a process
     find cold instruction caches and TLBs, the waves of a workgroup drift apart, and a missing barrier shows (the
     cross-group read map of round 2 produced wrong rows only here)."""
@@ -126,6 +126,7 @@ def cold_batch(rank, world_size, port, n, L, read_map, out_dir):
         import torch
         from tensornetworks_amd import backend as be
         dev = torch.device("cuda", 0)
+        be.set_option(dev, "reg_wires", int(reg_wires))
         be.set_option(dev, "read_map", int(read_map))
         P = be.num_params("hardware_efficient", n, L)
         g = torch.Generator().manual_seed(0)

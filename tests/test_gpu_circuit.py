@@ -21,12 +21,19 @@ def dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture()
-def be(dev):
+@pytest.fixture(params=[3, 4], ids=["r3", "r4"])
+def be(dev, request):
+    """Every test of this file runs under both persistent pass kernels: 8 amplitudes per thread (reg_wires = 3,
+    circuit_pass_r3_kernel, the default) and 16 per thread (reg_wires = 4, circuit_pass_fast_kernel, also the fallback of
+    plans the first cannot run)."""
     from tensornetworks_amd import backend
+    default_r = backend.get_option(dev, "reg_wires")
+    backend.set_option(dev, "reg_wires", request.param)
     yield backend
     backend.set_option(dev, "tile_bits", 13)          # restore the planner defaults
     backend.set_option(dev, "tile_bits_multi", 0)     # (0 = automatic: 2^13 tiles where the persistent kernel can run them)
+    backend.set_option(dev, "read_map", -1)           # (-1 = by the kernel: on with 8 amplitudes per thread)
+    backend.set_option(dev, "reg_wires", default_r)
 
 
 def gpu_probs(be, dev, ansatz, n, L, thetas):
@@ -313,7 +320,7 @@ def test_alternate_walk_is_bit_identical(be, dev, ansatz, n, L, kb, share):
 @pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
 @pytest.mark.parametrize("n,L,kb", [(14, 3, 11), (15, 3, 13), (16, 2, 12)])
 def test_read_map_planner_option(be, dev, ansatz, n, L, kb):
-    """Planner option read_map (off by default): phase-0 CNOTs may target thread-held wires; such a stage reads across
+    """Planner option read_map (default: on with 8 amplitudes per thread, off with 16): phase-0 CNOTs may target thread-held wires; such a stage reads across
     thread groups and carries a barrier between its reads and its write-back (STAGE_CROSS_READ -- without it the rows
     were wrong on a cold GPU, where the waves of a workgroup drift apart).  Fewer stages, same circuit: a batch large
     enough for several tiles per workgroup against the oracle, and against the default plan to rounding."""
@@ -322,11 +329,12 @@ def test_read_map_planner_option(be, dev, ansatz, n, L, kb):
     th = np.random.default_rng(3 * n + L).uniform(-np.pi, np.pi, P)
     tht = torch.as_tensor(th, device=dev)
     try:
-        ref = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
+        be.set_option(dev, "read_map", 0)
+        ref = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True).clone()
         be.set_option(dev, "read_map", 1)
         got = be.paramshift_probs(ansatz, n, L, tht, 0, P, include_base=True)
     finally:
-        be.set_option(dev, "read_map", 0)
+        be.set_option(dev, "read_map", -1)
     assert float((got.sum(dim=1) - 1).abs().max()) < 1e-12
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-10, atol=1e-14)
     np.testing.assert_allclose(got[0].cpu().numpy(), oc.probs(ansatz, n, L, th), rtol=RTOL, atol=ATOL)

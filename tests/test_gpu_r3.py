@@ -120,3 +120,62 @@ def test_r3_prefix_sharing_and_kron(be, dev):
     yd = K @ q
     assert float((y - yd).abs().max()) <= 1e-11 * float((K.abs() @ q).max())
     assert abs(ksd2.item() - float(q @ yd)) <= 1e-11 * float(q @ (K.abs() @ q))
+
+
+@pytest.mark.parametrize("ansatz,n,L,kb", [("hardware_efficient", 14, 3, 11), ("hardware_efficient", 15, 4, 13), ("all_to_all", 14, 2, 12),
+                                           ("basic", 15, 3, 13), ("hardware_efficient", 16, 2, 13)])
+def test_fused_dot_equals_stored_probabilities(be, dev, ansatz, n, L, kb):
+    """bornvi_paramshift_dot_begin / _finish: the parameter-shift dot product accumulated inside the shifted circuits'
+    last pass against the un-fused path (probabilities written, then bornvi_ksd_grad_finish): q bitwise, loss bitwise,
+    gradient to 1e-12 of its largest entry; a strided share of the parameters (one rank's deal) and the plain 1/2 scale;
+    deterministic (two runs bitwise equal).  The VJP is the one implied by ksd_vi_quantum.py:150."""
+    be.set_option(dev, "reg_wires", 3)
+    be.set_option(dev, "read_map", 1)
+    be.set_option(dev, "tile_bits", kb)
+    P = oc.num_params(ansatz, n, L)
+    rng = np.random.default_rng(n + L)
+    th = torch.as_tensor(rng.uniform(-np.pi, np.pi, P), device=dev)
+    w = torch.as_tensor(rng.standard_normal(1 << n), device=dev)
+    ksd2 = torch.tensor([3.7], dtype=torch.float64, device=dev)
+    assert be.paramshift_dot_supported(ansatz, n, L, dev, P)
+    for lo, hi, step in ((0, P, 1), (1, P, 3)):
+        cnt = len(range(lo, hi, step))
+        probs = be.paramshift_probs(ansatz, n, L, th, lo, hi, include_base=True, p_stride=step).clone()
+        loss_u, grad_u, _ = be.ksd_grad_finish(n, probs[1:], cnt, w, ksd2)
+        q, tok = be.paramshift_dot_begin(ansatz, n, L, th, lo, hi, p_stride=step)
+        loss_f, grad_f = be.paramshift_dot_finish(tok, w, ksd2)
+        assert torch.equal(q, probs[0]) and torch.equal(loss_f, loss_u)
+        tol = 1e-12 * float(grad_u.abs().max())
+        assert float((grad_f - grad_u).abs().max()) <= tol
+        q2, tok2 = be.paramshift_dot_begin(ansatz, n, L, th, lo, hi, p_stride=step)
+        loss_2, grad_2 = be.paramshift_dot_finish(tok2, w, ksd2)
+        assert torch.equal(grad_2, grad_f) and torch.equal(q2, q)
+        none, grad_h = be.paramshift_dot_finish(tok2, w, None)             # plain 1/2 (bornvi_paramshift_grad's scale)
+        ref_h = 0.5 * ((probs[1::2] - probs[2::2]) @ w)
+        assert none is None and float((grad_h - ref_h).abs().max()) <= 1e-12 * float(ref_h.abs().max())
+    # below the clamp of the loss the gradient is zero (torch's clamp backward, ksd_vi_quantum.py:145)
+    tiny = torch.tensor([1e-13], dtype=torch.float64, device=dev)
+    q, tok = be.paramshift_dot_begin(ansatz, n, L, th, 0, P)
+    loss_c, grad_c = be.paramshift_dot_finish(tok, w, tiny)
+    assert float(grad_c.abs().max()) == 0.0 and abs(loss_c.item() - 1e-6) < 1e-18
+    be.release_workspaces()
+
+
+def test_fused_dot_in_the_trainer_step(be, dev):
+    """KSDVariationalInference.ksd_and_grad with the fused dot (default where available) against the same step with
+    fused_dot = False, n = 14 dense: loss bitwise, gradient to 1e-12."""
+    from tensornetworks_amd.bayesian_network import synthetic_network
+    from tensornetworks_amd.ksd_vi_quantum import KSDVariationalInference
+    be.set_option(dev, "reg_wires", 3)
+    be.set_option(dev, "read_map", 1)
+    n, L = 14, 3
+    bn, lat, obs, x = synthetic_network(n, 0)
+    torch.manual_seed(0)
+    vi = KSDVariationalInference(bn, lat, obs, qbm_num_latent_vars=n, qbm_ansatz_layers=L, pytorch_device="cuda:0", gram_mode="dense")
+    vi._prepare_stein(x)
+    assert be.paramshift_dot_supported("hardware_efficient", n, L, dev, vi.born_machine.num_ansatz_params)
+    loss_f, grad_f, q_f = vi.ksd_and_grad()
+    vi.fused_dot = False
+    loss_u, grad_u, q_u = vi.ksd_and_grad()
+    assert torch.equal(q_f, q_u) and torch.equal(loss_f, loss_u)
+    assert float((grad_f - grad_u).abs().max()) <= 1e-12 * float(grad_u.abs().max())

@@ -139,15 +139,15 @@ def test_rccl_group_of_one_runs_the_collective_wrappers(dev, tmp_path):
     assert bool(np.load(tmp_path / "rccl.npz")["ok"])
 
 
-@pytest.mark.parametrize("read_map", [0, 1])
-def test_cold_process_runs_the_full_n20_batch_correctly(dev, tmp_path, read_map):
+@pytest.mark.parametrize("reg_wires,read_map", [(3, 1), (3, 0), (4, 0), (4, 1)])
+def test_cold_process_runs_the_full_n20_batch_correctly(dev, tmp_path, reg_wires, read_map):
     """Two fresh processes each run BASELINE config 4's batch (n = 20, L = 8, 961 circuits) as their FIRST GPU work:
     every row must sum to 1.  (A stage that read across thread groups without a barrier was right in every warm run
     and wrong in five of eight cold ones.)"""
     from oracle import cpu_port as cp, circuit as oc
     want, digests = None, []
     for trial in range(2):
-        codes = run_ranks(shard_worker.cold_batch, 1, (20, 8, read_map, str(tmp_path)), timeout=300)
+        codes = run_ranks(shard_worker.cold_batch, 1, (20, 8, read_map, str(tmp_path), reg_wires), timeout=300)
         assert codes == [0], (codes, _errors(tmp_path))
         res = np.load(tmp_path / "cold0.npz")
         assert float(res["worst"]) < 1e-12

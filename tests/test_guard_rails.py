@@ -37,7 +37,10 @@ def _fnv(words):
 
 CASES = [(0, 3, 4, 0), (0, 8, 4, 0), (0, 12, 4, 0), (0, 14, 3, 11), (0, 16, 6, 0), (0, 16, 2, 12), (0, 17, 2, 0),
          (1, 14, 2, 0), (1, 16, 6, 0), (2, 15, 3, 0), (2, 16, 6, 0), (0, 9, 3, 6), (0, 6, 3, 4), (2, 1, 1, 0),
-         (0, 20, 8, 0), (-1, 16, 0, 0), (-1, 20, 0, 0), (-1, 9, 0, 6), (0, 12, 2, 8), (0, 13, 2, 13)]
+         (0, 20, 8, 0), (-1, 16, 0, 0), (-1, 20, 0, 0), (-1, 9, 0, 6), (0, 12, 2, 8), (0, 13, 2, 13),
+         # the 3-register-wire plan (0x200) and its compact tables, with and without the read map (0x100)
+         (0, 16, 6, 0x200), (0, 16, 6, 0x300), (0, 20, 8, 0x300), (1, 14, 2, 0x200 | 11), (2, 15, 3, 0x300 | 12), (0, 12, 4, 0x300),
+         (-1, 20, 0, 0x200), (-1, 13, 0, 0x200 | 10), (0, 9, 2, 0x200), (1, 16, 3, 0x300)]
 
 
 def test_planner_under_address_and_ub_sanitizers(tmp_path):
@@ -69,6 +72,12 @@ def test_planner_under_address_and_ub_sanitizers(tmp_path):
         else:
             assert int(tok[8]) == len(F) and int(tok[9], 16) == _fnv(F), f"fast tables differ under the sanitizers: {line}"
         assert tok[11] == "1", f"a stage kind outside the fast kernel's switch: {line}"
+        if kb & 0x200:
+            Cw, _ = _ext.plan_compact_words(ansatz, n, L, kb & 0x1ff)
+            if Cw is None:
+                assert int(tok[13]) == 0, line
+            else:
+                assert int(tok[13]) == len(Cw) and int(tok[14], 16) == _fnv(Cw), f"compact tables differ under the sanitizers: {line}"
 
 
 @pytest.mark.parametrize("ansatz,n,L,kb", [(0, 16, 6, 0), (1, 16, 3, 0), (2, 16, 6, 0), (0, 20, 8, 0), (0, 14, 3, 11), (-1, 20, 0, 0)])
