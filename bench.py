@@ -119,11 +119,64 @@ def gate_apply_microbench(dev, n=16, total_bytes=4 << 30, reps=20, warm=5):
             a.record(); fn(); b.record()
         torch.cuda.synchronize(dev)
         ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
-        out["gbs"][name] = round(out["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+        # (a CNOT moves only the half of the state whose control bit is set: 16 * 2^n bytes per state, not 32 * 2^n)
+        nbytes = out["bytes_per_launch"] // 2 if name.startswith("cnot") else out["bytes_per_launch"]
+        out["gbs"][name] = round(nbytes / (ms * 1e-3) / 1e9, 1)
     vals = [v for k, v in out["gbs"].items() if k.startswith("ry")]
     out["ry_mean_gbs"] = round(float(np.mean(vals)), 1)
     out["frac_of_hbm_peak"] = round(out["ry_mean_gbs"] / HBM_PEAK_GBS, 4)
+    out["byte_model"] = "one-qubit gate: 32 * 2^n bytes per state (read + write every amplitude); CNOT: 16 * 2^n (the control = 1 half)"
     del st
+    return out
+
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: dense fp64 matrix peak (= the fp64 vector peak on gfx950)
+
+
+def mfma_extras(vi, dev, n):
+    """The two matrix-core kernels of the path, measured live on the trainer's own (padded) K_p: the batched contraction
+    Y = K_p Q^T (kernels_batched.hip: v_mfma_f64_16x16x4) for B = 128 and B = 2P + 1 distributions, and the Gram build
+    (kernels_stein.hip: gram_mfma_kernel, rank-3n bilinear form on 16 x 16 tiles; HBM-write bound)."""
+    from tensornetworks_amd import backend
+    N = 1 << n
+    out = {}
+    K = vi._K
+    if K is None or n < 8:
+        return None
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize(dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize(dev)
+        return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+    bq = {}
+    for B in (128, 2 * vi.born_machine.num_ansatz_params + 1):
+        Q = torch.rand((B, N), dtype=torch.float64, device=dev)
+        Q /= Q.sum(dim=1, keepdim=True)
+        ms = timed(lambda: backend.stein_quadform(K, Q, n, want_y=False))
+        flop = 2.0 * N * N * B
+        floor_ms = max(8.0 * N * N / (HBM_PEAK_GBS * 1e9), flop / (FP64_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+        bq[f"B{B}"] = {"ms": round(ms, 3), "tflops": round(flop / (ms * 1e-3) / 1e12, 2),
+                       "frac_of_fp64_mfma_peak": round(flop / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                       "roofline_floor_ms": round(floor_ms, 3), "over_floor": round(ms / floor_ms, 3)}
+        del Q
+    out["batched_quadform"] = {"kernel": "quadform_batched_kernel (v_mfma_f64_16x16x4_f64, 64 x 64 wave tiles) + rowdot",
+                               "K_row_pitch": int(K.stride(0)), "peak_tflops": FP64_MFMA_PEAK_TFLOPS, **bq,
+                               "note": "the KSD of B distributions at once (diagnostic of SURVEY 0.5); the training step needs B = 1"}
+    ld = int(K.stride(0))
+    scratch = torch.empty((N, ld), dtype=torch.float64, device=dev)[:, :N] if ld != N else torch.empty((N, N), dtype=torch.float64, device=dev)
+    ms = timed(lambda: backend.stein_gram(vi._S, n, vi.base_kernel_length_scale, out=scratch, ld=ld if ld != N else None))
+    flop = 2.0 * 3 * n * N * N                       # three rank-n products on the matrix cores
+    out["gram_build"] = {"kernel": f"gram_mfma_kernel<{n}>", "ms": round(ms, 3),
+                         "written_gbs": round(8.0 * N * N / (ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(8.0 * N * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "mfma_tflops": round(flop / (ms * 1e-3) / 1e12, 2),
+                         "note": "one-off per observation (outside the step); 8 * 4^n bytes written, 6 n 4^n flop on the matrix cores"}
+    del scratch
     return out
 
 
@@ -163,7 +216,7 @@ def b2_pennylane(ansatz, n, layers, theta64):
         return f"PennyLane importable but the B2 leg failed: {type(e).__name__}: {e}"
 
 
-def cpu_baseline(n, layers, ansatz, gram_mode, S_host, theta64):
+def cpu_baseline(n, layers, ansatz, gram_mode, S_host, theta64, max_params=None):
     """ONE full KSD-gradient step of the oracle's C port (oracle/cpu_port.c, OpenMP) on the host cores: all 2P + 1
     circuits, then the contraction in the same form the GPU leg uses -- dense: y = K_p q over the whole 2^n x 2^n matrix,
     streamed in freshly built 8 GiB row blocks (building K_p is outside the step, as on the GPU); kron: the matrix-free
@@ -177,9 +230,13 @@ def cpu_baseline(n, layers, ansatz, gram_mode, S_host, theta64):
     # OpenMP runtime loaded takes ~1 s)
     cp.circuit_probs("basic", 4, 1, np.zeros((2 * cp.max_threads(), 8)))
     cp.kron_matvec(np.zeros((64, 6)), np.full(64, 1.0 / 64), 6, 1.0)
+    # max_params (the n = 20 series leg): a BOUNDED sample -- the base circuit and the shifted circuits of the first
+    # max_params parameters are run and timed, the circuit and gradient-dot times are scaled to all 2P + 1 circuits (every
+    # circuit costs the same: same gates, same state size); the contraction is timed whole
+    Ps = P if (max_params is None or max_params >= P) else int(max_params)
     t0 = time.perf_counter()
-    probs, used = cp.paramshift_probs(ansatz, n, layers, theta64, 0, P, include_base=True)
-    t_circ = time.perf_counter() - t0
+    probs, used = cp.paramshift_probs(ansatz, n, layers, theta64, 0, Ps, include_base=True)
+    t_circ = (time.perf_counter() - t0) * (2 * P + 1) / (2 * Ps + 1)
     q = np.ascontiguousarray(probs[0])
     shifted = probs[1:]
     if gram_mode == "dense":
@@ -207,13 +264,15 @@ def cpu_baseline(n, layers, ansatz, gram_mode, S_host, theta64):
     ksd2 = float(q @ y)
     loss = math.sqrt(max(ksd2, 1e-12))
     grad = 0.5 * ((shifted[0::2] - shifted[1::2]) @ (y / loss))
-    t_fin = time.perf_counter() - tf
+    t_fin = (time.perf_counter() - tf) * P / Ps
     step_s = t_circ + t_gemv + t_fin
     return {"value": round(1.0 / step_s, 6), "unit": "steps/s", "cores": int(used), "kind": "port",
             "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads(),
-            "sample": f"one full step: {probs.shape[0]} circuits ({t_circ:.2f} s) + {form} + gradient dots "
-                      f"({t_fin * 1e3:.0f} ms), oracle/cpu_port.c with OpenMP, nothing extrapolated",
-            "step_seconds": round(step_s, 3), "loss": loss, "grad_norm": float(np.linalg.norm(grad)),
+            "sample": (f"one full step: {probs.shape[0]} circuits ({t_circ:.2f} s) + {form} + gradient dots "
+                       f"({t_fin * 1e3:.0f} ms), oracle/cpu_port.c with OpenMP, nothing extrapolated") if Ps == P else
+                      (f"bounded sample: {probs.shape[0]} of the step's {2 * P + 1} circuits run and timed (scaled to {t_circ:.1f} s for all: "
+                       f"every circuit is the same work) + {form} + gradient dots (scaled, {t_fin * 1e3:.0f} ms), oracle/cpu_port.c with OpenMP"),
+            "step_seconds": round(step_s, 3), "loss": loss, "grad_norm": float(np.linalg.norm(grad)) if Ps == P else None,
             "b2_pennylane": b2_pennylane(ansatz, n, layers, theta64)}
 
 
@@ -374,7 +433,7 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
             "gram_mode": gram_mode}
 
 
-def pmc_traffic(workload, passes, tile_bits):
+def pmc_traffic(workload, passes, tile_bits, variant="r4"):
     """Measured HBM bytes per launch from a rocprofv3 --pmc run of THIS plan (tools/pmc_traffic.sh + pmc_summarize.py),
     newest matching file under profiles/; a file whose recorded plan signature differs is ignored."""
     best = None
@@ -384,7 +443,7 @@ def pmc_traffic(workload, passes, tile_bits):
         except Exception:
             continue
         sig = d.get("signature")
-        if sig and (sig.get("passes"), sig.get("tile_bits")) == (passes, tile_bits):
+        if sig and (sig.get("passes"), sig.get("tile_bits"), sig.get("kernel", "r4")) == (passes, tile_bits, variant):
             best = (f, d)
     if best is None:
         return {}, None
@@ -408,13 +467,32 @@ def kernel_table(m, D, args):
     vi, P, n, layers, ansatz, gram_mode = m["vi"], m["P"], m["n"], m["layers"], m["ansatz"], m["gram_mode"]
     world = D.world
     timers = m["timers"]
-    plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)   # same defaults as the handle
+    from tensornetworks_amd import backend
+    dev = vi._S.device
+    # the plan the handle runs: 8 amplitudes per thread (reg_wires = 3, the default, with the read map) where eligible
+    reg_wires, read_map = backend.get_option(dev, "reg_wires"), backend.get_option(dev, "read_map")
+    plan_flags = args.tile_bits
+    compact = None
+    if reg_wires == 3:
+        rm_flag = 0x100 if read_map != 0 else 0           # (-1 = by the kernel: on with reg_wires = 3)
+        compact = _ext.plan_compact_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits | rm_flag)
+        if compact[0] is not None:
+            plan_flags = args.tile_bits | rm_flag | _ext.R3
+        else:
+            compact = None
+    if compact is None and read_map == 1:
+        plan_flags |= 0x100
+    plan = _ext.plan_words(_ext.ANSATZ_IDS[ansatz], n, layers, plan_flags)
     n_passes, n_gates = int(plan[3]), int(plan[11])
     circuits_rank = 1 + 2 * len(range(0, P, world))            # rank 0: the parameters 0, W, 2W, ...
     circ_ms, stein_ms, fin_ms = mean_ms(timers.get("circuits")), mean_ms(timers.get("stein")), mean_ms(timers.get("finish"))
     base_ms = mean_ms(timers.get("base_circuit"))     # > 0 only in overlap mode: base circuit launched separately
-    circ_launches = n_passes * (2 if base_ms > 0 else 1)
-    circ_kernel_ms = circ_ms + base_ms
+    # the parameter-shift dot fused into the shifted circuits' last pass (bornvi_paramshift_dot_*): that pass runs inside
+    # the trainer's "finish" span (with the tiny partial-sum kernel and the all-gather, whose span is subtracted)
+    fused_dot = bool(getattr(vi, "fused_dot", False)) and not vi.overlap_streams and vi.grad_engine == "paramshift" and \
+        backend.paramshift_dot_supported(ansatz, n, layers, dev, len(range(0, P, world)))
+    circ_launches = n_passes * (2 if base_ms > 0 else 1) + (1 if fused_dot else 0)
+    circ_kernel_ms = circ_ms + base_ms + (max(fin_ms - mean_ms(timers.get("allgather")), 0.0) if fused_dot else 0.0)
     N = 1 << n
     unfused_bytes = 32.0 * N * n_gates * circuits_rank
     first_pass = _ext.plan_param_first_pass(plan)[list(range(0, P, world))] if n_passes > 1 else None
@@ -425,15 +503,19 @@ def kernel_table(m, D, args):
     w0 = r1 = 1.0
     zero_note = ""
     if n_passes > 2 and not any(o.startswith(("zero_support=0", "direct_stages=")) for o in args.opt) and not args.debug_flags:
-        fw = _ext.plan_fast_words(_ext.ANSATZ_IDS[ansatz], n, layers, args.tile_bits)
+        slots = 8 if compact is not None else 16
+        fw = compact if compact is not None else _ext.plan_fast_words(_ext.ANSATZ_IDS[ansatz], n, layers, plan_flags)
+        zword = 6 if compact is not None else 7                # CH_ZINFO / FH_ZINFO of a pass header
         if fw[0] is not None:
-            gmask, zslots = int(fw[0][fw[1][0] + 7]), int(fw[0][fw[1][1] + 7]) & 0xFFFF
-            w0, r1 = 0.5 ** bin(gmask).count("1"), (16 - bin(zslots).count("1")) / 16.0
+            gmask, zslots = int(fw[0][fw[1][0] + zword]), int(fw[0][fw[1][1] + zword]) & 0xFFFF
+            w0, r1 = 0.5 ** bin(gmask).count("1"), (slots - bin(zslots).count("1")) / float(slots)
             if gmask:
                 zero_note = (f"; pass 0 writes {w0:.4g} of a state (tiles outside the support of |0..0> that nobody reads are "
                              f"left out), pass 1 reads {r1:.4g} of one (slots known to be zero are not loaded)")
+    # (last pass: 8 * 2^n probabilities per circuit -- with the fused dot only the base circuit writes them)
     circ_bytes = sum(a * ((16.0 * N * (r1 if i == 1 else 1.0) if i > 0 else 0.0) +
-                          (16.0 * N * (w0 if i == 0 else 1.0) if i < n_passes - 1 else 8.0 * N)) for i, a in enumerate(active))
+                          (16.0 * N * (w0 if i == 0 else 1.0) if i < n_passes - 1 else (8.0 * N / a if fused_dot else 8.0 * N)))
+                     for i, a in enumerate(active))
     rows_rank = -(-N // world)
     sym = gram_mode == "dense" and vi.symmetric_contraction and (world == 1 or vi._K_pairs is not None)
     stein_name = ("quadform_sym_kernel" if sym else "quadform_kernel") if gram_mode == "dense" else "kron_matvec"
@@ -459,7 +541,8 @@ def kernel_table(m, D, args):
         stein_bytes = full_bytes
     pmc, pmc_src = ({}, None)
     if world == 1 and not args.prefix_share:
-        pmc, pmc_src = pmc_traffic(args.workload if m.get("is_main") else "", n_passes, int(plan[2]))
+        pmc, pmc_src = pmc_traffic(m.get("workload", args.workload if m.get("is_main") else ""), n_passes, int(plan[2]),
+                                   "r3" if compact is not None else "r4")
     t_circ = next((kv.get("hbm_bytes_per_launch") for kname, kv in pmc.items() if kname.startswith("circuit_pass")), None)
     t_stein = None
     if sym:
@@ -467,6 +550,10 @@ def kernel_table(m, D, args):
         t_stein = sum(parts) if parts else None
     kern = {
         "circuit_pass_kernel": {"bound": "hbm", "launches_per_step": circ_launches,
+                                "kernel": ("circuit_pass_r3_kernel (8 amplitudes per thread, four waves per SIMD" +
+                                           (", read map" if plan_flags & 0x100 else "") + ")") if compact is not None
+                                          else "circuit_pass_fast_kernel (16 amplitudes per thread, two waves per SIMD)",
+                                "fused_paramshift_dot": fused_dot,
                                 "achieved": round(circ_bytes / (circ_kernel_ms * 1e-3) / 1e9, 1) if circ_ms else None,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(circ_kernel_ms, 4),
                                 "avg_launch_ms": round(circ_kernel_ms / circ_launches, 4),
@@ -667,6 +754,7 @@ def main(argv=None):
     m = measure(args.workload, dev, D, args, args.steps, args.warmup, args.repeats,
                 want_extras=not args.debug_flags and not args.no_extras)
     m["is_main"] = True
+    m["workload"] = args.workload
     kern, config, phases = kernel_table(m, D, args)
     med_ms, rep = summarize(m, args.steps)
     phases_per_rank = D.gather_objects({"rank": rank, **phases})
@@ -701,6 +789,9 @@ def main(argv=None):
         }
         if selftest is not None:
             rec["dist_selftest"] = selftest
+    if rank == 0 and world == 1 and m["gram_mode"] == "dense" and not args.no_extras and not args.debug_flags and vi._K is not None:
+        # the two matrix-core kernels of the path on this run's own K_p (MFMA utilisation against the fp64 matrix peak)
+        rec["extras"]["mfma"] = mfma_extras(vi, dev, m["n"])
     S_host = vi._S.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     theta0, main_n = m["theta0"], m["n"]
     main_cfg = (m["n"], m["layers"], m["ansatz"], m["gram_mode"])
@@ -715,6 +806,7 @@ def main(argv=None):
             raise SystemExit(f"unknown --series workload {series_name}")
         ks = max(3, min(args.steps, 10))
         ms_ = measure(series_name, dev, D, args, ks, 2, 3, want_extras=False)
+        ms_["workload"] = series_name
         kern_s, config_s, phases_s = kernel_table(ms_, D, args)
         med_s, rep_s = summarize(ms_, ks)
         pr_s = D.gather_objects({"rank": rank, **phases_s})
@@ -723,6 +815,15 @@ def main(argv=None):
                               "unit": "steps/s", "n_gpus": world, "ms_per_step": round(med_s, 4), "repeats": rep_s,
                               "config": config_s, "kernels": kern_s, "phase_ms": phases_s, "phase_ms_per_rank": pr_s,
                               "scaling": "strong", "loss_first_last": [float(ms_["losses"][0]), float(ms_["losses"][-1])]}]
+            dom_s = max(kern_s, key=lambda k_: kern_s[k_]["ms_per_step"])
+            rec["series"][0]["roofline"] = {**kern_s[dom_s], "kernel_row": dom_s}
+            if world == 1 and not args.no_cpu_baseline:
+                # the same step on the host cores (oracle's C port: all 2P + 1 circuits + the contraction in the form the GPU leg uses)
+                n_s, layers_s, ansatz_s, gram_s = WORKLOADS[series_name]
+                cb = cpu_baseline(n_s, layers_s, ansatz_s, gram_s, ms_["vi"]._S.cpu().numpy(), ms_["theta0"], max_params=48)
+                rec["series"][0]["cpu_baseline"] = cb
+                if cb:
+                    rec["series"][0]["gpu_over_cpu"] = round(rec["series"][0]["value"] / cb["value"], 1)
         del ms_
         backend.release_workspaces()
         torch.cuda.empty_cache()

@@ -44,12 +44,15 @@ for k in sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"])):
     kern[k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
                "launches_sampled": int(max(nf, nw))}
 # the plan these bytes belong to: bench.py shows the traffic only while the library still plans the same passes
+workload = sys.argv[4] if len(sys.argv) > 4 else "n16_L6_dense"
+variant = sys.argv[5] if len(sys.argv) > 5 else "r3"          # the pass kernel of the profiled run (r3: 8 amplitudes per thread, read map)
 sys.path.insert(0, REPO)
 from tensornetworks_amd import _ext  # noqa: E402  (host-only planner entry point: no GPU needed)
-plan = _ext.plan_words(_ext.ANSATZ_IDS["hardware_efficient"], 16, 6, 0)
-signature = {"workload": "n16_L6_dense", "passes": int(plan[3]), "tile_bits": int(plan[2]), "commit": commit}
+n_w, l_w = int(workload.split("_")[0][1:]), int(workload.split("_")[1][1:])
+plan = _ext.plan_words(_ext.ANSATZ_IDS["hardware_efficient"], n_w, l_w, (_ext.R3 | 0x100) if variant == "r3" else 0)
+signature = {"workload": workload, "passes": int(plan[3]), "tile_bits": int(plan[2]), "kernel": variant, "commit": commit}
 rec = {"signature": signature, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench.py --steps 2 "
-                 "--warmup 1, workload n16_L6_dense" + (" -- " + note if note else ""),
+                 f"--warmup 1, workload {workload}" + (" -- " + note if note else ""),
        "correction": "gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read -> fetch bytes = 2 * FETCH_SIZE * 1024; "
                      "WRITE_SIZE * 1024 exact (MI355X_MICROARCH.md, HBM)",
        "kernels": kern}
