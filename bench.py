@@ -50,7 +50,9 @@ WORKLOADS = {
     "n12_L4_dense": (12, 4, "hardware_efficient", "dense"),
 }
 ADV_WORKLOADS = {"adv_n12_b65536": (12, 4, 65536)}     # BASELINE config 5: (n, layers, REINFORCE batch)
-SERIES_WORKLOAD = "n20_L8_kron"     # BASELINE config 4: reported beside the headline at every N
+# reported beside the headline at every N: BASELINE config 4; the headline's circuit with the matrix-free contraction; config 2
+SERIES_WORKLOADS = ("n20_L8_kron", "n16_L6_kron", "n8_L4_dense")
+SERIES_WORKLOAD = SERIES_WORKLOADS[0]
 
 
 def mean_ms(pairs):
@@ -799,9 +801,12 @@ def main(argv=None):
     backend.release_workspaces()
     torch.cuda.empty_cache()
 
-    # ---- BASELINE config 4 (n = 20, L = 8, matrix-free) beside the headline, same protocol, at every N ----
-    series_name = {"auto": SERIES_WORKLOAD if args.workload == "n16_L6_dense" else "none"}.get(args.series, args.series)
-    if series_name != "none" and not args.debug_flags:
+    # ---- beside the headline, same protocol, at every N: BASELINE config 4 (n = 20, L = 8, matrix-free), the headline's
+    # circuit with the matrix-free contraction (what gram_mode="auto" weighs against the dense form) and config 2 (n = 8) ----
+    series_names = {"auto": list(SERIES_WORKLOADS) if args.workload == "n16_L6_dense" else [], "none": []}.get(args.series, [args.series])
+    if args.debug_flags:
+        series_names = []
+    for series_name in series_names:
         if series_name not in WORKLOADS:
             raise SystemExit(f"unknown --series workload {series_name}")
         ks = max(3, min(args.steps, 10))
@@ -811,19 +816,21 @@ def main(argv=None):
         med_s, rep_s = summarize(ms_, ks)
         pr_s = D.gather_objects({"rank": rank, **phases_s})
         if rank == 0:
-            rec["series"] = [{"workload": series_name, "metric": "ksd_gradient_steps_per_sec", "value": round(1e3 / med_s, 4),
-                              "unit": "steps/s", "n_gpus": world, "ms_per_step": round(med_s, 4), "repeats": rep_s,
-                              "config": config_s, "kernels": kern_s, "phase_ms": phases_s, "phase_ms_per_rank": pr_s,
-                              "scaling": "strong", "loss_first_last": [float(ms_["losses"][0]), float(ms_["losses"][-1])]}]
+            entry = {"workload": series_name, "metric": "ksd_gradient_steps_per_sec", "value": round(1e3 / med_s, 4),
+                     "unit": "steps/s", "n_gpus": world, "ms_per_step": round(med_s, 4), "repeats": rep_s,
+                     "config": config_s, "kernels": kern_s, "phase_ms": phases_s, "phase_ms_per_rank": pr_s,
+                     "launch": "one HIP graph replay per step (make_graphed_step)" if ms_["graph"] else "eager kernel launches",
+                     "scaling": "strong", "loss_first_last": [float(ms_["losses"][0]), float(ms_["losses"][-1])]}
             dom_s = max(kern_s, key=lambda k_: kern_s[k_]["ms_per_step"])
-            rec["series"][0]["roofline"] = {**kern_s[dom_s], "kernel_row": dom_s}
-            if world == 1 and not args.no_cpu_baseline:
-                # the same step on the host cores (oracle's C port: all 2P + 1 circuits + the contraction in the form the GPU leg uses)
+            entry["roofline"] = {**kern_s[dom_s], "kernel_row": dom_s}
+            if world == 1 and not args.no_cpu_baseline and series_name == SERIES_WORKLOADS[0]:
+                # the same step on the host cores (oracle's C port: circuits + the contraction in the form the GPU leg uses)
                 n_s, layers_s, ansatz_s, gram_s = WORKLOADS[series_name]
                 cb = cpu_baseline(n_s, layers_s, ansatz_s, gram_s, ms_["vi"]._S.cpu().numpy(), ms_["theta0"], max_params=48)
-                rec["series"][0]["cpu_baseline"] = cb
+                entry["cpu_baseline"] = cb
                 if cb:
-                    rec["series"][0]["gpu_over_cpu"] = round(rec["series"][0]["value"] / cb["value"], 1)
+                    entry["gpu_over_cpu"] = round(entry["value"] / cb["value"], 1)
+            rec.setdefault("series", []).append(entry)
         del ms_
         backend.release_workspaces()
         torch.cuda.empty_cache()

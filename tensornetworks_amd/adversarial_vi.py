@@ -144,6 +144,24 @@ class AdversarialVariationalInference:
                                            torch.zeros(batch_size, 1, device=self.device)), dim=0)
         return self._label_cache
 
+    @staticmethod
+    def _reinforce_reward(logit_d, log_p, baseline, first, baseline_decay):
+        """reference :202-215: raw reward = classifier logit - log p(x|z); the running baseline (a 0-dim tensor, updated
+        IN PLACE: the tensor a captured epoch reads and writes) is the first epoch's mean reward, then an exponential
+        average; returns the reward with the updated baseline applied."""
+        raw_reward = logit_d - log_p
+        mean_reward = raw_reward.mean()
+        if first:
+            baseline.copy_(mean_reward)
+        else:
+            baseline.mul_(baseline_decay).add_(mean_reward, alpha=1 - baseline_decay)
+        return raw_reward - baseline
+
+    @staticmethod
+    def _reinforce_loss(log_q, reinforce_reward):
+        """reference :217-222: loss_q = mean(log q(z) * reward - entropy bonus), entropy bonus = -0.01 log q(z)."""
+        return (log_q * reinforce_reward.detach() - (-0.01 * log_q)).mean()
+
     def _born_step(self, batch_size, x_obs_tensor, with_x, optimizer_born, clip, baseline_decay, first):
         """reference :184-231: REINFORCE with a running baseline and an entropy bonus.  ONE differentiable q_theta
         evaluation serves the sampling and log q (the reference runs the circuit twice); the baseline is a device scalar;
@@ -159,15 +177,9 @@ class AdversarialVariationalInference:
                 z_q = self._bits(idx.to(self.device))
                 logit_d = self.classifier(self._clf_inputs(z_q, x_obs_tensor, with_x)).squeeze()
                 log_p = self._log_p_active[idx.to(self.device)]       # (the table of this observation, built by train())
-                raw_reward = logit_d - log_p
-                mean_reward = raw_reward.mean()
-                if first:                                             # (in place: the tensor a captured epoch reads and writes)
-                    self._baseline.copy_(mean_reward)
-                else:
-                    self._baseline.mul_(baseline_decay).add_(mean_reward, alpha=1 - baseline_decay)
-                reinforce_reward = raw_reward - self._baseline
+                reinforce_reward = self._reinforce_reward(logit_d, log_p, self._baseline, first, baseline_decay)
             log_q = torch.log(q.clamp(min=1e-9))[idx].to(self.device)
-            loss_q = (log_q * reinforce_reward - (-0.01 * log_q)).mean()
+            loss_q = self._reinforce_loss(log_q, reinforce_reward)
         with self._spans("born_backward"):
             finite = torch.isfinite(loss_q.detach())
             fused_ok = theta.is_cuda and optimizer_born.defaults.get("fused")
@@ -238,6 +250,7 @@ class AdversarialVariationalInference:
         criterion_classifier = nn.BCEWithLogitsLoss()
         self._baseline = torch.zeros((), device=self.device)
         self._found_inf = torch.zeros((), dtype=torch.float32, device=self.device)
+        self._last_good_norm = torch.zeros((), dtype=torch.float32, device=self.device)
         self._label_cache = None
         self._log_p_active = self._log_p_table(x_obs_tensor)   # built once, outside the epochs (its key is a host read-back)
         self.graph_error = None
@@ -262,18 +275,21 @@ class AdversarialVariationalInference:
             for _ in range(k_classifier_steps):
                 loss_d, grad_norm_d = self._classifier_step(batch_size, x_obs_tensor, with_x, optimizer_classifier,
                                                             criterion_classifier, gradient_clip_norm)
-            loss_q = grad_norm_q = finite = None
+            loss_q = finite = None
             n_skip = torch.zeros((), dtype=torch.int64, device=self.device)
             for _ in range(k_born_steps):
                 loss_q, gn, finite = self._born_step(batch_size, x_obs_tensor, with_x, optimizer_born, gradient_clip_norm,
                                                      baseline_decay, first=first)
+                # history['grad_norm_born'] = the norm of the last update that WAS applied (the reference's grad_norm_q
+                # survives skipped steps and epochs, 0.0 before the first good one, adversarial_vi.py:224-231): kept in a
+                # device scalar, updated in place (a captured epoch reads and writes the same tensor)
                 if gn is not None:
-                    grad_norm_q = gn
+                    self._last_good_norm.copy_(torch.where(finite, gn.detach().to(self._last_good_norm.dtype), self._last_good_norm))
                 n_skip = n_skip + (~finite).to(torch.int64)
             return (loss_d if loss_d is not None else nan_t,
                     grad_norm_d.detach() if grad_norm_d is not None else zero_t,
                     torch.where(finite, loss_q, nan_t.to(loss_q.dtype)) if loss_q is not None else nan_t,
-                    grad_norm_q.detach() if grad_norm_q is not None else zero_t, n_skip)
+                    self._last_good_norm.clone(), n_skip)
 
         graph = graph_out = side = None
         self.graphed_epochs = 0             # epochs of this call replayed from the graph

@@ -123,6 +123,19 @@ struct DeviceScope {
   DeviceScope dev_scope_((h)->device);     \
   HIPCHK(h, dev_scope_.err)
 
+// Plans, tables and share tables are uploaded through the NULL stream; the kernels that read them run on the caller's
+// stream, which (torch's streams) does not synchronise with it: one device-wide wait per NEW plan / table.  That wait is
+// illegal while a stream capture is active -- a captured region must find its plans built (run the call once eagerly
+// before capturing, as make_graphed_step and the adversarial epoch graph do); say so instead of a bare HIP error.
+int sync_uploads(bornvi_handle h) {
+  const hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) return BORNVI_OK;
+  if (e == hipErrorStreamCaptureUnsupported || e == hipErrorStreamCaptureInvalidated || e == hipErrorStreamCaptureImplicit)
+    return fail(h, BORNVI_ERR_HIP, std::string("a new circuit plan or table had to be built while a stream capture was active (") +
+                                       hipGetErrorString(e) + "): run this call once eagerly with the same options before capturing");
+  return fail(h, BORNVI_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+}
+
 int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
   auto key = std::make_tuple(ansatz, n, layers);
   auto it = h->plans.find(key);
@@ -160,7 +173,7 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
     dp->r3_workgroups = circuit_r3_workgroups_per_cu(1 << (dp->plan.k - 3), dp->r3_lds) * h->num_cus;
     if (dp->r3_workgroups <= 0) return fail(h, BORNVI_ERR_HIP, "circuit_pass_r3_kernel: no workgroup fits a CU");
     std::vector<uint32_t>().swap(dp->compact.words);
-    HIPCHK(h, hipDeviceSynchronize());
+    { int rc_ = sync_uploads(h); if (rc_) return rc_; }
     *out = dp.get();
     h->plans[key] = std::move(dp);
     return BORNVI_OK;
@@ -186,7 +199,7 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
   }
   // The uploads above go through the NULL stream; the kernels that read them are launched on the caller's stream, which
   // (torch's streams) does not synchronise with it.  One device-wide wait per NEW plan.
-  HIPCHK(h, hipDeviceSynchronize());
+  { int rc_ = sync_uploads(h); if (rc_) return rc_; }
   *out = dp.get();
   h->plans[key] = std::move(dp);
   return BORNVI_OK;
@@ -321,7 +334,7 @@ int get_share_tables(bornvi_handle h, DevPlan* dp, int p_begin, int p_count, int
     tabs->chunks.push_back(std::move(ch));
     if (codes.empty()) break;
   }
-  HIPCHK(h, hipDeviceSynchronize());      // (NULL-stream uploads, read by kernels on the caller's stream: see get_plan)
+  { int rc_ = sync_uploads(h); if (rc_) return rc_; }      // (NULL-stream uploads, read by kernels on the caller's stream: see get_plan)
   *out = tabs.get();
   dp->share_cache.push_back(std::move(tabs));
   return BORNVI_OK;
@@ -448,6 +461,13 @@ bool build_adj_plan(int ansatz, int n, int layers, AdjPlan& out, std::string& ms
   }
   flush_rots();
   if (!flush_ent()) { msg = "too many CZ gates in one entangler block"; return false; }
+  // adj_reduce_kernel writes grad[p] once per slot: a parameter shared by two gates would be overwritten, not summed
+  std::vector<int> uses((size_t)(out.n_params > 0 ? out.n_params : 0), 0);
+  for (const AdjRotBlock& b : out.rots)
+    for (int e = 0; e < b.nrot; ++e)
+      if (b.param[e] >= 0) {
+        if (b.param[e] >= out.n_params || ++uses[(size_t)b.param[e]] > 1) { msg = "adjoint engine: a parameter is carried by more than one gate"; return false; }
+      }
   return true;
 }
 
@@ -464,7 +484,7 @@ int get_adj_plan(bornvi_handle h, int ansatz, int n, int layers, AdjPlan** out) 
   DEVICE_SCOPE(h);
   HIPCHK(h, hipMalloc((void**)&ap->d_slot_param, slots.size() * sizeof(int)));
   HIPCHK(h, hipMemcpy(ap->d_slot_param, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(h, hipDeviceSynchronize());      // (NULL-stream uploads, read by kernels on the caller's stream: see get_plan)
+  { int rc_ = sync_uploads(h); if (rc_) return rc_; }      // (NULL-stream uploads, read by kernels on the caller's stream: see get_plan)
   *out = ap.get();
   h->adj_plans[key] = std::move(ap);
   return BORNVI_OK;
@@ -1118,6 +1138,8 @@ int bornvi_adjoint_vjp(bornvi_handle h, int ansatz, int n, int layers, const dou
       std::swap(lam, lam2);
     }
   }
+  // (a parameter no gate carries keeps gradient 0; every parameter sits in exactly one slot -- build_adj_plan checks it)
+  HIPCHK(h, hipMemsetAsync(grad, 0, (size_t)(ap->n_params > 0 ? ap->n_params : 0) * sizeof(double), st));
   HIPCHK(h, launch_adj_reduce(partials, ap->d_slot_param, 4 * (int)ap->rots.size(), nwg, grad, st));
   return BORNVI_OK;
 }
@@ -1125,7 +1147,7 @@ int bornvi_adjoint_vjp(bornvi_handle h, int ansatz, int n, int layers, const dou
 int bornvi_debug_circuit_stamps(bornvi_handle h, unsigned long long* out16) {
   if (!h || !out16) return BORNVI_ERR_INVALID;
   DEVICE_SCOPE(h);
-  HIPCHK(h, hipDeviceSynchronize());
+  { int rc_ = sync_uploads(h); if (rc_) return rc_; }
   HIPCHK(h, read_circuit_stamps(out16));
   return BORNVI_OK;
 }

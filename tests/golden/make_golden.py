@@ -175,6 +175,63 @@ def adversarial_tables():
     print("adversarial_tables:", {k: v.shape for k, v in out.items()})
 
 
+def reinforce_trace():
+    """The Born-machine (REINFORCE) step of the reference's adversarial trainer (adversarial_vi.py:184-231), epoch by epoch:
+    a spy around the sampler, the classifier, log p(x|z) and log q records what the step consumed and produced -- sample
+    indices, classifier logits, log p(x|z), log q, the running baseline after the step and loss_q -- for 4 epochs of the
+    reference's own train() on the Sprinkler network (classical Born machine, seeded).  The build's _reinforce_loss is
+    fed the same per-step inputs and must return the same baseline and loss."""
+    import adversarial_vi as ref_adv
+    torch.manual_seed(11)
+    np.random.seed(11)
+    bn, lat, obs = ref_bn.get_sprinkler_network(False), ['C', 'S', 'R'], ['W']
+    adv = ref_adv.AdversarialVariationalInference(bn, lat, obs, born_machine_config={'use_logits': True, 'conditioning_dim': 0},
+                                                  classifier_config={}, device='cpu')
+    outs = ref_utils.generate_all_binary_outcomes(len(lat))
+    rec = {"idx": [], "logits": [], "log_p": [], "log_q": [], "q": []}
+    state = {"in_born": False}
+    bm, clf = adv.born_machine, adv.classifier
+    orig_logq, orig_logp, orig_fwd = bm.get_log_q_z_x, adv._get_log_p_x_given_z, clf.forward
+
+    def spy_logq(z, xc=None):                      # called once per Born step, after the classifier and log p
+        out = orig_logq(z, xc)
+        rec["idx"].append(np.array([outs.index(tuple(int(v) for v in row)) for row in z.tolist()]))
+        rec["log_q"].append(out.detach().numpy().copy())
+        rec["q"].append(bm.get_probabilities(xc).detach().squeeze().numpy().copy())
+        rec["logits"].append(state.pop("last_logits"))
+        rec["log_p"].append(state.pop("last_logp"))
+        return out
+
+    def spy_logp(x, z):
+        out = orig_logp(x, z)
+        state["last_logp"] = out.detach().numpy().copy()
+        return out
+
+    def spy_fwd(x):
+        out = orig_fwd(x)
+        state["last_logits"] = out.detach().squeeze().numpy().copy()      # (the Born step's call is the last one before log q)
+        return out
+
+    bm.get_log_q_z_x, adv._get_log_p_x_given_z, clf.forward = spy_logq, spy_logp, spy_fwd
+    with contextlib.redirect_stdout(io.StringIO()):
+        hist = adv.train({'W': 1}, num_epochs=4, batch_size=64, lr_born_machine=0.01, lr_classifier=0.01, k_classifier_steps=1,
+                         k_born_steps=1, verbose=False, baseline_decay=0.9)
+    # the reference keeps its running baseline in a local: recompute it from the recorded rewards exactly as :208-212 does,
+    # and check the recomputation against the recorded loss_q before writing anything
+    base, bases, losses = 0.0, [], []
+    for e in range(4):
+        raw = torch.tensor(rec["logits"][e]) - torch.tensor(rec["log_p"][e])
+        base = raw.mean().item() if e == 0 else 0.9 * base + 0.1 * raw.mean().item()
+        bases.append(base)
+        lq = torch.tensor(rec["log_q"][e])
+        losses.append(float((lq * (raw - base) - (-0.01 * lq)).mean()))
+    assert np.allclose(losses, hist['loss_born_machine'], rtol=1e-6, atol=1e-7), (losses, hist['loss_born_machine'])
+    np.savez(os.path.join(HERE, "reinforce_trace.npz"), idx=np.array(rec["idx"]), logits=np.array(rec["logits"]),
+             log_p=np.array(rec["log_p"]), log_q=np.array(rec["log_q"]), q=np.array(rec["q"]), baseline=np.array(bases),
+             loss_q=np.array(hist['loss_born_machine']), baseline_decay=np.float64(0.9))
+    print("reinforce_trace: loss_q", hist['loss_born_machine'], "baseline", bases)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-n8", action="store_true")
@@ -182,6 +239,7 @@ if __name__ == "__main__":
     args = ap.parse_args()
     if args.only_adversarial:
         adversarial_tables()
+        reinforce_trace()
         sys.exit(0)
     two_node_kat()
     sprinkler_case("w1", ref_bn.get_sprinkler_network(False), {'W': 1})
@@ -194,6 +252,7 @@ if __name__ == "__main__":
     synthetic_case(5, 1)
     classical_trace()
     adversarial_tables()
+    reinforce_trace()
     if not args.skip_n8:
         # 32 of the 256 rows of K (each row = 256 reference k_p calls), full S
         synthetic_case(8, 0, rows=list(range(0, 256, 8)))

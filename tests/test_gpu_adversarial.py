@@ -128,3 +128,33 @@ def test_classifier_batch_split_gradient_equals_the_plain_layers():
     for a, b in zip(ga, gb):
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), float((a - b).abs().max())
     assert list(clf.state_dict().keys()) == [f"network.{i}.{k}" for i in (0, 2, 4) for k in ("weight", "bias")]
+
+
+def test_skipped_born_updates_keep_the_last_applied_norm():
+    """A NaN / Inf Born loss skips that update (reference adversarial_vi.py:224-231): history['loss_born_machine'] holds
+    NaN for the epoch and history['grad_norm_born'] the norm of the last update that WAS applied -- 0.0 before the first.
+    The loss of two epochs is made NaN (the running baseline stays finite)."""
+    import torch
+    bn, lat, obs, x = synthetic_network(5, 3, p_low=0.25, p_high=0.75)
+    torch.manual_seed(3)
+    adv = make(bn, lat, obs, layers=2)
+    orig = type(adv)._reinforce_loss
+    calls = {"n": 0}
+
+    def poisoned(log_q, reward):            # epochs 0 and 3: a NaN loss (the baseline itself stays finite)
+        bad = calls["n"] in (0, 3)
+        calls["n"] += 1
+        out = orig(log_q, reward)
+        return out * float('nan') if bad else out
+
+    type(adv)._reinforce_loss = staticmethod(poisoned)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            hist = adv.train(x, num_epochs=5, batch_size=256, lr_born_machine=0.01, lr_classifier=0.01, verbose=False,
+                             graph_epochs=False)
+    finally:
+        type(adv)._reinforce_loss = staticmethod(orig)
+    lb, gn = hist['loss_born_machine'], hist['grad_norm_born']
+    assert np.isnan(lb[0]) and np.isnan(lb[3]) and np.all(np.isfinite([lb[1], lb[2], lb[4]]))
+    assert gn[0] == 0.0 and gn[1] > 0 and gn[2] > 0 and gn[3] == gn[2] and np.isfinite(gn[4]) and gn[4] > 0
+    assert torch.isfinite(adv.born_machine.theta).all()

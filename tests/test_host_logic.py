@@ -378,3 +378,25 @@ def test_bench_refuses_a_world_size_that_is_not_gpus(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2"])
     assert "WORLD_SIZE=3" in str(e.value)
+
+
+def test_reinforce_step_against_the_reference_trace():
+    """The Born-machine (REINFORCE) step of the adversarial trainer against a trace captured from the reference's own
+    train() (adversarial_vi.py:184-231; tests/golden/make_golden.py: reinforce_trace -- sample indices, classifier logits,
+    log p(x|z), log q, running baseline and loss_q of 4 epochs): the build's reward / baseline / loss arithmetic, fed the
+    reference's per-step inputs, reproduces the reference's baseline and loss_q; log q comes from the build's own
+    expression log(clamp(q, 1e-9))[index] on the reference's q (quantum_born_machine.py:180-201)."""
+    import torch
+    from tensornetworks_amd.adversarial_vi import AdversarialVariationalInference as A
+    g = golden("reinforce_trace.npz")
+    decay = float(g["baseline_decay"])
+    baseline = torch.zeros(())
+    for e in range(len(g["loss_q"])):
+        logits, log_p = torch.tensor(g["logits"][e]), torch.tensor(g["log_p"][e])
+        idx = torch.tensor(g["idx"][e], dtype=torch.long)
+        log_q = torch.log(torch.tensor(g["q"][e]).clamp(min=1e-9))[idx]
+        np.testing.assert_allclose(log_q.numpy(), g["log_q"][e], rtol=1e-6, atol=1e-7)
+        rr = A._reinforce_reward(logits, log_p, baseline, e == 0, decay)
+        loss_q = A._reinforce_loss(log_q, rr)
+        assert abs(baseline.item() - g["baseline"][e]) <= 1e-6 * abs(g["baseline"][e])
+        assert abs(loss_q.item() - g["loss_q"][e]) <= 1e-6 * max(1.0, abs(g["loss_q"][e])), (e, loss_q.item(), g["loss_q"][e])
