@@ -31,6 +31,12 @@ namespace bornvi {
 #ifndef BORNVI_R3_MAT_UPFRONT
 #define BORNVI_R3_MAT_UPFRONT 1    // 1: the stage's matrices are requested together, ahead of the amplitude reads; 0: each one in front of its gate (A/B)
 #endif
+#ifndef BORNVI_R3_NO_LDS_READ
+#define BORNVI_R3_NO_LDS_READ 0    // 1: a stage does not read its amplitudes from LDS (what the read half of the round trip costs)
+#endif
+#ifndef BORNVI_R3_NO_LDS_WRITE
+#define BORNVI_R3_NO_LDS_WRITE 0   // 1: a stage does not write its results back to LDS
+#endif
 #ifndef BORNVI_R3_NO_GATES
 #define BORNVI_R3_NO_GATES 0       // 1: the stages' LDS round trips and signs without the gate arithmetic
 #endif
@@ -117,7 +123,11 @@ __device__ __forceinline__ void put_slot(double xr, double xi, int jj, char* __r
     if (FIN) async_store8(ha, (xr * xr + xi * xi) * scale, hbm_base);
     else async_store16(ha, (d2_t){xr, xi}, hbm_base);
   } else {
+#if BORNVI_R3_NO_LDS_WRITE
+    asm volatile("" : : "v"(xr), "v"(xi), "v"(wa0 ^ comb3(jj, WB)));
+#else
     *reinterpret_cast<double2*>(lds + (wa0 ^ comb3(jj, WB))) = make_double2(xr, xi);
+#endif
   }
 }
 
@@ -169,8 +179,12 @@ __device__ __forceinline__ void stage8(char* __restrict__ lds, const char* __res
     const uint32_t ra0 = (my_rw & 0xffffu) << 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+#if BORNVI_R3_NO_LDS_READ
+      asm volatile("" : "=v"(ar[j]), "=v"(ai[j]) : "v"(ra0 ^ comb3(j, RB)));
+#else
       const double2 x = *reinterpret_cast<const double2*>(lds + (ra0 ^ comb3(j, RB)));
       ar[j] = x.x; ai[j] = x.y;
+#endif
     }
     if (cross) {      // the read map took amplitudes from other threads' groups (plan.hpp: STAGE_CROSS_READ)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -20,7 +20,7 @@ stats = OrderedDict()
 steps = 0
 for a, b in zip(heads, heads[1:]):
     names = [rows[i][2] for i in range(a, b)]
-    if not any("shift_dot_kernel" in x for x in names) or any("gram" in x for x in names):
+    if not any(("shift_dot_kernel" in x) or ("dot_finish_kernel" in x) for x in names) or any("gram" in x for x in names):
         continue                       # not a training step (a probability evaluation, a set-up phase)
     steps += 1
     for i in range(a, b):
