@@ -13,7 +13,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(pat, recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].replace("bornvi::", "")
+        k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0].replace("bornvi::", "")
         if flt not in k:
             continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
