@@ -170,7 +170,7 @@ int get_plan(bornvi_handle h, int ansatz, int n, int layers, DevPlan** out) {
       HIPCHK(h, prepare_circuit_r3_kernel(dp->r3_lds));
       h->max_r3_lds_prepared = dp->r3_lds;
     }
-    dp->r3_workgroups = circuit_r3_workgroups_per_cu(1 << (dp->plan.k - 3), dp->r3_lds) * h->num_cus;
+    dp->r3_workgroups = circuit_r3_workgroups_per_cu(dp->plan.threads, dp->r3_lds) * h->num_cus;
     if (dp->r3_workgroups <= 0) return fail(h, BORNVI_ERR_HIP, "circuit_pass_r3_kernel: no workgroup fits a CU");
     std::vector<uint32_t>().swap(dp->compact.words);
     { int rc_ = sync_uploads(h); if (rc_) return rc_; }
@@ -362,7 +362,7 @@ int circuit_batch(bornvi_handle h, int ansatz, int n, int layers, long long batc
   char* base = (char*)ws;
   double* gates = (double*)base;
   const size_t gates_bytes = align_up((size_t)bc_max * gate_slots(p) * 64, 256);
-  const int normalise = dp->d_compact ? 1 : 0;
+  const int normalise = dp->d_compact ? (p.n_passes == 1 ? 2 : 1) : 0;   // (2: records without the scale kernel, see launch_build_gates)
   const size_t state_bytes = align_up((size_t)bc_max * ((size_t)16 << n), 256);
   void* bufA = base + gates_bytes;
   void* bufB = base + gates_bytes + state_bytes;
@@ -725,7 +725,7 @@ bool dot_layout(const Plan& p, int n, int p_count, DotLayout& L) {
 }
 // the fused path exists for multi-pass plans of the 8-amplitude kernel, without prefix sharing
 bool dot_supported(bornvi_handle h, DevPlan* dp) {
-  return dp->d_compact && dp->plan.n_passes >= 2 && !h->prefix_share && h->grad_engine == 0;
+  return dp->d_compact && dp->plan.n_passes >= 2 && dp->plan.k >= 9 && !h->prefix_share && h->grad_engine == 0;
 }
 // input buffer of pass i when pass 0 starts from |0..0> and writes bufA first
 void* pass_input_buffer(int i, void* bufA, void* bufB) { return i == 0 ? nullptr : ((i & 1) ? bufA : bufB); }
@@ -1049,8 +1049,10 @@ int bornvi_ksd_grad_finish(bornvi_handle h, int n, const double* shifted, int n_
     return fail(h, BORNVI_ERR_INVALID, "bad argument");
   DEVICE_SCOPE(h);
   hipStream_t st = (hipStream_t)stream;
-  if (dLdq_out || loss_out) HIPCHK(h, launch_dldq(y, ksd2, n, dLdq_out, loss_out, st));
-  HIPCHK(h, launch_shift_dot(shifted, n_shift, y, ksd2, n, grad, nullptr, st));
+  // (the loss alone rides on the dot kernel -- one launch less for the latency-bound sizes; dL/dq needs its own pass)
+  const bool loss_by_dot = loss_out && !dLdq_out && n_shift > 0;
+  if (dLdq_out || (loss_out && !loss_by_dot)) HIPCHK(h, launch_dldq(y, ksd2, n, dLdq_out, loss_out, st));
+  HIPCHK(h, launch_shift_dot(shifted, n_shift, y, ksd2, n, grad, loss_by_dot ? loss_out : nullptr, st));
   return BORNVI_OK;
 }
 

@@ -1309,7 +1309,8 @@ hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* th
   const int bs = 128;
   build_gates_kernel<<<dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st>>>(
       plan, thetas, theta_stride, shift_mode, p_begin, p_stride, include_base, b_offset, batch, gates, shift_tab, slots, normalise);
-  if (normalise) gate_scale_kernel<<<dim3((unsigned)batch), dim3(64), 0, st>>>(gates, nfused, slots, batch);
+  // (normalise == 2: a single-pass plan -- the pass kernel multiplies the pivots itself, one launch less)
+  if (normalise == 1) gate_scale_kernel<<<dim3((unsigned)batch), dim3(64), 0, st>>>(gates, nfused, slots, batch);
   return hipGetLastError();
 }
 

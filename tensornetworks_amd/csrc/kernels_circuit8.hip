@@ -282,7 +282,8 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
   uint32_t H[CH_WORDS];
 #pragma unroll
   for (int i = 0; i < CH_WORDS; ++i) H[i] = C[i];
-  const uint32_t t = threadIdx.x, T = blockDim.x;     // T == 2^(k-3): 8 tile elements per thread
+  // T == max(64, 2^(k-3)) threads; the first 2^(k-3) hold 8 tile elements each (tiles below 2^9: part of one wave)
+  const uint32_t t = threadIdx.x, T = blockDim.x;
   const uint32_t lane = t & 63u, wv = t >> 6;
   const int kt = k - 3;
   const uint32_t ksize = 1u << k;
@@ -371,6 +372,9 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     uint32_t lane_t = lane, wv_t = wv;
     asm volatile("" : "+v"(lane_t), "+v"(wv_t));
     const uint32_t t_t = (wv_t << 6) | lane_t;
+    // (tiles below 2^9: only the first 2^(k-3) lanes of the one wave hold amplitudes; the fused-dot instantiation is
+    // offered for tiles of whole waves only)
+    const bool active = DOT ? true : t_t < (ksize >> 3);
     const bool has_next = Snext < total_tiles;
     long long Tcur, Tnext;
     if (zskip) {     // INIT pass: the one non-zero tile of every circuit first, spread over all workgroups, then the zero tiles
@@ -389,7 +393,21 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
     const bool noop_tile = zero_tile && (g & zgmask) != 0u;
     const char* __restrict__ gb = reinterpret_cast<const char*>(gates + b * gate_stride);   // this circuit's fused matrices
     // (normalised gates: the pivots' |p|^2 multiply back into the probabilities; slot nfused of the circuit's gate array)
-    const double scale = (fin && real) ? *reinterpret_cast<const double*>(gb + (size_t)plan[PH_NFUSED] * 64u) : 1.0;
+    double scale = 1.0;
+    if (fin && real) {
+      if (!DOT && init) {
+        // a single-pass plan (one tile per circuit): the wave multiplies the circuit's |p|^2 itself -- the same lane split
+        // and butterfly as gate_scale_kernel (same bits), which the launch-bound sizes then need not launch
+        const uint32_t nf_ = plan[PH_NFUSED];
+        double sc_ = 1.0;
+        for (uint32_t f_ = lane_t; f_ < nf_; f_ += 64u) sc_ *= reinterpret_cast<const double*>(gb)[f_ * 8u + 6u];
+#pragma unroll
+        for (int off_ = 32; off_ > 0; off_ >>= 1) sc_ *= __shfl_xor(sc_, off_, 64);
+        scale = sc_;
+      } else {
+        scale = *reinterpret_cast<const double*>(gb + (size_t)plan[PH_NFUSED] * 64u);
+      }
+    }
     double2* dst = out + b * state_stride;
     double* pdst = probs + (b << n);
     if (fin && share.row_map) {
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
       // the tile has arrived in registers: all but this wave's 8 tile-out stores are done (DOT: a trip issues no stores)
       if (DOT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      if (DOT && g != g_w) {      // the thread's 8 weights of this tile row (the grid keeps a workgroup on one row: once per launch)
+      if (DOT && g != g_w && active) {      // the thread's 8 weights of this tile row (the grid keeps a workgroup on one row: once per launch)
         g_w = g;
         const uint32_t o_ = direct_out ? (lane_tab[row_out_d * 64u + lane_t] ^ uni_tab[row_out_d * NW + wv_t])
                                        : (lane_tab[row_out_n * 64u + lane_t] ^ uni_tab[row_out_n * NW + wv_t]);
@@ -414,12 +432,12 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
       if (init) {
         if (!zero_tile)
           for (uint32_t u = t_t; u < ksize; u += T) tile[u] = make_double2((u == 0 && g == 0) ? 1.0 : 0.0, 0.0);
-      } else if (!direct_in) {
+      } else if (!direct_in && active) {
         const uint32_t slot_t = (lane_tab[row_slot * 64u + lane_t] ^ uni_tab[row_slot * NW + wv_t]) & 0xffffu;
 #pragma unroll
         for (int i = 0; i < 8; ++i) tile[slot_t ^ comb3(i, fill_step)] = make_double2(v[i].x, v[i].y);
       }
-      if (direct_in) BORNVI_RUN_STAGE8(0, 1);
+      if (direct_in && active) BORNVI_RUN_STAGE8(0, 1);
       asm volatile("" ::: "memory");
     }
     // ---- the registers are free: the next tile starts its trip from HBM now (the only load site) ----
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
         g_pref = gn_;
         in_uni = UNI[((size_t)gn_ * nrows + row_in) * NW + (tt_ >> 6)];
       }
-      if (!init) {
+      if (!init && active) {
         const uint32_t base_ = lane_tab[row_in * 64u + (tt_ & 63u)] ^ in_uni;
         const double2* src_ = in + (bn_ >= share.fresh_begin ? 0ll : bn_) * state_stride;
 #pragma unroll
@@ -444,14 +462,14 @@ __global__ __launch_bounds__(1024) void circuit_pass_r3_kernel(
       __syncthreads();                          // the tile (or the first stage's result) is in LDS
       for (int s = direct_in ? 1 : 0; s < (zero_tile ? 0 : nstages); ++s) {
         if (s == nstages - 1 && direct_out) {
-          BORNVI_RUN_STAGE8(s, 2);
+          if (active) BORNVI_RUN_STAGE8(s, 2);
         } else {
-          BORNVI_RUN_STAGE8(s, 0);
+          if (active) BORNVI_RUN_STAGE8(s, 0);
           __syncthreads();
         }
       }
       // ---- tile out: exactly 8 vector-memory stores per wave (the vmcnt waits count them), here or in the last stage ----
-      if (noop_tile) {
+      if (noop_tile || !active) {
       } else if (zero_tile) {
         const uint32_t off0 = (xor_cols16(t_t, kt, P + PW_OUT_COL) ^ xor_cols16(g, gbits, P + PW_OUT_GCOL)) << out_shift;
 #pragma unroll
@@ -530,11 +548,11 @@ hipError_t launch_circuit_pass_r3(const uint32_t* plan, uint32_t pass_off, const
   const long long per_state = 1ll << (n - k);
   if (wgs > per_state) wgs -= wgs % per_state;      // a workgroup keeps its tile row: its table rows stay in LDS
   if (wdot)
-    circuit_pass_r3_kernel<true><<<dim3((unsigned)wgs), dim3(1u << (k - 3)), lds, st>>>(
+    circuit_pass_r3_kernel<true><<<dim3((unsigned)wgs), dim3(k >= 9 ? 1u << (k - 3) : 64u), lds, st>>>(
         plan, pass_off, ctab, ct_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles,
         direct_mask, share, wdot, partials);
   else
-    circuit_pass_r3_kernel<false><<<dim3((unsigned)wgs), dim3(1u << (k - 3)), lds, st>>>(
+    circuit_pass_r3_kernel<false><<<dim3((unsigned)wgs), dim3(k >= 9 ? 1u << (k - 3) : 64u), lds, st>>>(
         plan, pass_off, ctab, ct_off, (const double2*)in, (double2*)out, probs, gates, gate_stride, 1ll << n, total_tiles,
         direct_mask, share, nullptr, nullptr);
   return hipGetLastError();

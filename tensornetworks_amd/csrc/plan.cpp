@@ -1134,9 +1134,10 @@ bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg
   out = CompactTables();
   const int n = plan.n, k = plan.k, r = plan.r;
   if (r != 3) { msg = "compact tables: the plan must have 3 register wires"; return false; }
-  if (k < 9 || plan.threads != (1 << (k - 3)) || n - k > 16 || n > 27) { msg = "compact tables: tile below 2^9 or state too large"; return false; }
+  // (tiles of 2^6 .. 2^8 amplitudes: one wave whose first 2^(k-3) lanes hold amplitudes -- the launch-bound sizes n <= 8)
+  if (k < 6 || plan.threads != std::max(64, 1 << (k - 3)) || n - k > 16 || n > 27) { msg = "compact tables: tile below 2^6 or state too large"; return false; }
   const int kt = k - 3, gbits = n - k;
-  const uint32_t T = 1u << kt, NW = T / 64u, ngl = 1u << gbits, ksize = 1u << k;
+  const uint32_t T = 1u << kt, NW = std::max(T / 64u, 1u), ngl = 1u << gbits, ksize = 1u << k;
   std::vector<uint32_t>& W = out.words;
   auto fail = [&](const std::string& m) { msg = "compact tables: " + m; out = CompactTables(); return false; };
   for (int i = 0; i < plan.n_passes; ++i) {
@@ -1244,8 +1245,8 @@ bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg
         inv_in.assign(ksize, 0);
         for (uint32_t u = 0; u < ksize; ++u) inv_in[in_slot_lin(u)] = u;
         for (int b = 0; b < 3; ++b) in_basis[b] = in_phys_u(inv_in[W[hb + CH_WORDS + CS_RB + b] >> 4]) << 4;
-        ok_in = P[PW_LO_IN] >= 4u;
         const uint32_t lanes = 1u << std::min<uint32_t>(P[PW_LO_IN], 6u);
+        ok_in = P[PW_LO_IN] >= 4u && lanes <= T;
         const uint32_t runmask = lanes * 16u - 1u;
         std::vector<uint32_t> row(T);
         for (uint32_t g = 0; g < ngl && ok_in; ++g) {
@@ -1271,6 +1272,7 @@ bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg
         const uint32_t runmask = (lanes_o << out_shift) - 1u;
         if (P[PW_LO_OUT] < 4u && !(pflags & PASS_FINAL)) ok_out = false;
         if ((pflags & PASS_FINAL) && P[PW_LO_OUT] < 3u) ok_out = false;
+        if (lanes_o > T) ok_out = false;
         std::vector<uint32_t> row(T);
         for (uint32_t g = 0; g < ngl && ok_out; ++g) {
           for (uint32_t t = 0; t < T; ++t) row[t] = out_d(g, t);
@@ -1361,14 +1363,14 @@ bool build_compact_tables(const Plan& plan, CompactTables& out, std::string& msg
       const bool is_sign = row >= nst && row < nst + nsign;
       const uint32_t f00 = row_eval(row, 0, 0);
       uint32_t* LANE = W.data() + hb + lane_off + (size_t)row * 64;
-      for (uint32_t l = 0; l < 64; ++l) LANE[l] = row_eval(row, 0, l);
+      for (uint32_t l = 0; l < 64; ++l) LANE[l] = l < T ? row_eval(row, 0, l) : 0u;
       for (uint32_t g = 0; g < ngl; ++g)
         for (uint32_t w = 0; w < NW; ++w) {
           const uint32_t fgw = row_eval(row, g, 64u * w);
           W[hb + uni_off + ((size_t)g * nrows + row) * NW + w] = fgw ^ f00;
           if (is_sign) {
             uint32_t mpre = 0, mpost = 0;
-            for (int b = 0; b < 6; ++b) {
+            for (int b = 0; b < 6 && b < kt; ++b) {
               const uint32_t d = row_eval(row, g, 64u * w + (1u << b)) ^ LANE[1u << b] ^ fgw ^ f00;
               mpre |= (d & 1u) << b;
               mpost |= ((d >> 16) & 1u) << b;

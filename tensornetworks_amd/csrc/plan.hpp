@@ -16,6 +16,7 @@
 // (scalar) loads.  Layout constants below are shared with kernels_circuit.hip and with the
 // Python plan emulator in tests/.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -249,7 +250,7 @@ struct CompactTables {
   int max_rows = 0, max_sign = 0, max_stages = 0;
   // LDS of circuit_pass_r3_kernel: tile | LANE | UNI (one tile row) | MASK | wave sums
   size_t lds_bytes(int k) const {
-    const size_t nw = ((size_t)1 << (k - 3)) / 64;
+    const size_t nw = std::max<size_t>(((size_t)1 << (k - 3)) / 64, 1);
     return ((size_t)16 << k) + (size_t)max_rows * 64 * 4 + (size_t)max_rows * nw * 4 + (size_t)(max_sign > 0 ? max_sign : 1) * nw * 4 + 8 + nw * 8 + 64;   // (+ the waves' partial sums of the fused dot)
   }
 };

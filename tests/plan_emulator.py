@@ -402,7 +402,7 @@ def run_plan_compact(W, compact, mats, state_in=None, direct=3, zero_support=Tru
         C = int(Coffs[pi])
         H = [int(x) for x in Cw[C: C + CH_WORDS]]
         nst, nrows, nsign, NW = H[CH_NSTAGES], H[CH_NROWS], H[CH_NSIGN], H[CH_NWAVES]
-        assert nst == int(P[PW_NSTAGES]) and NW == max(T // 64, 1) and int(P[PW_THREADS]) == T
+        assert nst == int(P[PW_NSTAGES]) and NW == max(T // 64, 1) and int(P[PW_THREADS]) == max(64, T)
         sign_any = H[CH_SIGN_PRE] | H[CH_SIGN_POST]
         init, fin = bool(flags & PASS_INIT), bool(flags & PASS_FINAL)
         out_shift = 3 if fin else 4

@@ -75,8 +75,8 @@ def test_fast_tables_against_oracle(ansatz, n, L, kb):
 
 
 @pytest.mark.parametrize("ansatz", oc.ANSATZ_TYPES)
-@pytest.mark.parametrize("n,L,kb,read_map", [(9, 1, 0, 0), (11, 2, 9, 0), (12, 3, 0, 1), (13, 2, 11, 0), (14, 2, 12, 1), (14, 3, 11, 1),
-                                             (15, 3, 12, 0)])
+@pytest.mark.parametrize("n,L,kb,read_map", [(6, 3, 0, 0), (7, 2, 0, 0), (8, 4, 0, 0), (9, 3, 6, 0), (10, 2, 7, 0), (9, 1, 0, 0), (11, 2, 9, 0),
+                                             (12, 3, 0, 1), (13, 2, 11, 0), (14, 2, 12, 1), (14, 3, 11, 1), (15, 3, 12, 0)])
 def test_r3_plan_and_compact_tables_against_oracle(ansatz, n, L, kb, read_map):
     """The plan with 3 register wires per stage (8 amplitudes per thread, circuit_pass_r3_kernel): (i) its stage headers
     interpreted as the generic kernel does, (ii) its per-(tile row, thread) fast tables, (iii) its COMPACT tables -- every
@@ -86,7 +86,7 @@ def test_r3_plan_and_compact_tables_against_oracle(ansatz, n, L, kb, read_map):
     aid = _ext.ANSATZ_IDS[ansatz]
     flags = kb | _ext.R3 | (0x100 if read_map else 0)
     W = _ext.plan_words(aid, n, L, flags)
-    assert int(W[pe.PH_R]) == 3 and int(W[pe.PH_THREADS]) == max(64, 1 << (int(W[pe.PH_K]) - 3))
+    assert int(W[pe.PH_R]) == 3 and int(W[pe.PH_THREADS]) == max(64, 1 << (int(W[pe.PH_K]) - 3))    # (tiles below 2^9: part of one wave)
     th = np.random.default_rng(n * 13 + L).uniform(-np.pi, np.pi, oc.num_params(ansatz, n, L))
     ref = oc.probs(ansatz, n, L, th)
     mats = pe.fused_matrices(W, th)
