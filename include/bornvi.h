@@ -74,12 +74,14 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
 /* Tuning knobs of the circuit planner (clears the plan cache): "tile_bits" (4..13, amplitudes per
  * LDS tile = 2^tile_bits, for every n), "tile_bits_multi" (tile size used only when the state needs
  * several tiles; default 0 = chosen per plan: 13 wherever the persistent kernel can run such tiles, else 11), "low_bits" (0..8, contiguous 16-byte elements per HBM run =
- * 2^low_bits), "max_threads" (64..512); "debug_flags" (timing-only ablations of the circuit kernel:
+ * 2^low_bits), "max_threads" (64..1024); "debug_flags" (timing-only ablations of the circuit kernel:
  * results are INVALID while non-zero).  Engine switches (no effect on results): "fast_path",
  * "fast_workgroups_per_cu", "workgroups_per_cu", "direct_stages", "circuit_cus", "zero_support" (default 1: the first two passes of a circuit from |0..0> leave out what the support of that state makes
- * known zeros -- tiles nobody reads are not written, slots known to be zero are not loaded), "read_map" (default 0: the
- * planner may fold phase-0 CNOTs on thread-held wires into a stage's read map; fewer stages, but such a stage needs a
- * barrier between its reads and its write-back and measures slower; clears the plan cache), "alternate_walk" (default 1: odd passes
+ * known zeros -- tiles nobody reads are not written, slots known to be zero are not loaded), "reg_wires" (default 3: plans with 8 amplitudes per thread for the pass kernel that holds four waves per SIMD, wherever
+ * such a plan is eligible; 4: 16 amplitudes per thread, two waves per SIMD -- also the fallback; clears the plan cache),
+ * "read_map" (default -1 = by the kernel: the planner may fold phase-0 CNOTs on thread-held wires into a stage's read map --
+ * fewer stages, but such a stage needs a barrier between its reads and its write-back: faster with 8 amplitudes per
+ * thread, slower with 16; 0 / 1 force it; clears the plan cache), "alternate_walk" (default 1: odd passes
  * walk the tiles of the batch from the last to the first, so that a pass starts on the states the previous one wrote last --
  * the ones the memory-side cache still holds), "batched_quadform" (0: bornvi_stein_quadform
  * with B > 1 runs B GEMV passes instead of one matrix-core pass); "grad_engine" (default 0 = the reference's
