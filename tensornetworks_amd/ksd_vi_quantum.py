@@ -598,7 +598,8 @@ class KSDVariationalInference:
             return out
 
         step.graph = graph
-        return step
+        step.found_inf = found        # the captured kernels write and read this tensor on every replay: it lives as long
+        return step                   # as step() does (freed, its block is handed to the caller's next small tensor)
 
     def training_step(self, params, optimizer_born, scheduler, gradient_clip_norm):
         """One epoch body (reference :111-161) without the logging: device step, NaN/Inf guard, clip,

@@ -408,6 +408,29 @@ def test_graphed_step_replays_the_async_step(dev):
         vi2.make_graphed_step(p2, o2, s2, 10.0)
 
 
+def test_graphed_step_writes_only_memory_it_owns(dev):
+    """A replay writes through pointers fixed at capture time.  Every tensor behind them has to live as long as step()
+    does: one freed after the capture (the guard flag was, once) has its block handed to the caller's next small
+    tensor, and the next replay writes 0.0 into that.  Small tensors allocated after the capture keep their values."""
+    import gc
+    n, L = 8, 2
+    bn, lat, obs, x = synthetic_network(n, 5)
+    vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=3, gram_mode="dense")
+    vi._prepare_stein(x)
+    params, opt, sched = vi.make_optimizer(0.05, 12, True, "adam", (0.9, 0.999), capturable=True)
+    step = vi.make_graphed_step(params, opt, sched, 10.0, warmup=2)
+    gc.collect()
+    canaries = [torch.full((k,), 7.0, dtype=torch.float32, device=dev) for k in (1, 1, 1, 2, 8, 32, 64, 128) for _ in range(16)]
+    kept = []
+    for _ in range(4):
+        kept.append(tuple(t.clone() for t in step()))
+        canaries += [torch.full((), 7.0, dtype=torch.float32, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    assert all(bool((c == 7.0).all()) for c in canaries)
+    norms = [float(k[1]) for k in kept]
+    assert all(g > 0 for g in norms), norms
+
+
 @pytest.mark.parametrize("n,L,opt,with_tvd", [(3, 2, "adam", True), (3, 2, "sgd", False), (8, 2, "adam", False), (8, 1, "adam", True)])
 def test_train_without_host_sync_returns_the_same_history(dev, n, L, opt, with_tvd, capsys):
     """train(host_sync=False): the reference's epochs without the per-epoch loss.item() -- training_step_async, or for
