@@ -378,7 +378,10 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
     if use_graph:
         # latency-bound sizes: the whole step (circuits, contraction, gradient, clip, Adam) replayed from ONE HIP graph
         graphed = vi.make_graphed_step(*opt_state, clip, warmup=max(3, warmup))
-        step_fn = lambda params, opt, sched, clip_: tuple(t.clone() if i == 0 else t for i, t in enumerate(graphed()))
+        if graphed.adam is not None:      # the optimiser kernel records every epoch's loss on the device: nothing to clone
+            step_fn = lambda params, opt, sched, clip_: graphed()
+        else:
+            step_fn = lambda params, opt, sched, clip_: tuple(t.clone() if i == 0 else t for i, t in enumerate(graphed()))
     else:
         for _ in range(warmup):
             losses.append(step_fn(*opt_state, clip)[0])
@@ -429,6 +432,8 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
         extra_adjoint = {"grad_engine": "adjoint", "steps_per_sec": round(steps / e3, 4), "ms_per_step": round(1e3 * e3 / steps, 4),
                          "note": "opt-in (SURVEY 8(f) row 4): adjoint differentiation replaces the 2P parameter-shift circuit "
                                  "evaluations; eager launches, gate-block kernels (kernels_adjoint.hip)"}
+    if use_graph and graphed.adam is not None:
+        losses = graphed.adam.history()[0].cpu().tolist()      # all epochs, the graph's eager warm-up steps included
     return {"vi": vi, "P": P, "theta0": theta0, "elapsed": elapsed, "timers": timers, "losses": losses, "graph": use_graph,
             "extra_adjoint": extra_adjoint,
             "precompute_s": precompute_s, "extra_share": extra_share, "n": n, "layers": layers, "ansatz": ansatz,

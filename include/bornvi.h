@@ -302,6 +302,27 @@ int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, do
                                 const double* loss, float* grad32, float* total_norm,
                                 float* found_inf, bornvi_stream stream);
 
+/* The whole optimiser hand-off of one epoch in one launch, for the latency-bound sizes (a HIP-graph replay of the step
+ * spends most of its nodes in the optimiser otherwise): the clip and guard above, then the update of
+ * optim.Adam(lr, betas) (ksd_vi_quantum.py:92-99; eps as given, no weight decay, no amsgrad) on the float32 theta:
+ *   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
+ *   theta -= (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),
+ * moments and theta in float32, the products with the double hyper-parameters in double (as torch's fused kernel).
+ * A NaN / +-Inf loss leaves theta, the moments and t untouched ("Skipping update", :147-148).
+ *   theta dev [P] float32 (in/out); grad32 dev [P] float32 (out: the clipped gradient, what theta.grad holds);
+ *   theta64 dev [P] float64 (out: the updated theta, the next epoch's circuit input);
+ *   exp_avg, exp_avg_sq dev [P] float32 (in/out, zero before the first step);
+ *   counters dev [2] int32 (in/out, zero before the first step): [0] = t, good steps so far; [1] = epochs so far;
+ *   lr_table dev [n_lr] float64: the learning rate of epoch e at lr_table[min(e, n_lr - 1)] (the cosine schedule of
+ *   :100-103 tabulated by the host; the epoch count advances on a skipped epoch too, like scheduler.step() at :158);
+ *   loss_history dev [n_lr] float64, norm_history dev [n_lr] float32, or NULL: the same entry receives this epoch's
+ *   loss and gradient norm (history['loss_ksd'] / ['grad_norm'], :163-166, without a copy per epoch). */
+int bornvi_clip_adam_step(bornvi_handle h, int P, const double* grad64, double max_norm,
+                          const double* loss, float* theta, float* grad32, double* theta64,
+                          float* exp_avg, float* exp_avg_sq, int* counters, const double* lr_table,
+                          int n_lr, double beta1, double beta2, double eps, float* total_norm,
+                          double* loss_history, float* norm_history, bornvi_stream stream);
+
 /* ---- adjoint differentiation: OPT-IN second gradient engine ---------------------------
  * The reference differentiates with diff_method="parameter-shift" (quantum_born_machine.py:58, :90, :114): 2P circuit
  * evaluations.  For L = f(q) the same gradient is  dL/dtheta_k = Im <lambda_k| P_k |phi_k>  (one forward and one

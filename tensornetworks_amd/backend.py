@@ -142,6 +142,33 @@ def clip_cast_grad_guard(grad64, max_norm, loss, out=None, found_out=None):
     return g32, norm, found
 
 
+def clip_adam_step(grad64, max_norm, loss, theta, grad32, theta64, exp_avg, exp_avg_sq, counters, lr_table, beta1, beta2,
+                   eps, norm_out=None, loss_history=None, norm_history=None):
+    """clip_cast_grad_guard + the Adam update of float32 theta + the float64 copy of the new theta, one launch
+    (bornvi_clip_adam_step).  All tensors on the GPU and updated in place; -> the gradient's float32 norm [0-dim]."""
+    dev = grad64.device
+    h = _ext.handle_for(dev)
+    P = grad64.numel()
+    _chk(grad64, torch.float64, dev, "grad64")
+    _chk(loss, torch.float64, dev, "loss")
+    for t, dt, nm in ((theta, torch.float32, "theta"), (grad32, torch.float32, "grad32"), (theta64, torch.float64, "theta64"),
+                      (exp_avg, torch.float32, "exp_avg"), (exp_avg_sq, torch.float32, "exp_avg_sq")):
+        _chk(t, dt, dev, nm, P)
+    _chk(counters, torch.int32, dev, "counters", 2)
+    _chk(lr_table, torch.float64, dev, "lr_table")
+    norm = norm_out if norm_out is not None else torch.empty((), dtype=torch.float32, device=dev)
+    _chk(norm, torch.float32, dev, "norm_out", 1)
+    if loss_history is not None:
+        _chk(loss_history, torch.float64, dev, "loss_history", lr_table.numel())
+    if norm_history is not None:
+        _chk(norm_history, torch.float32, dev, "norm_history", lr_table.numel())
+    h.call("bornvi_clip_adam_step", P, _ptr(grad64), float(max_norm), _ptr(loss), _ptr(theta), _ptr(grad32), _ptr(theta64),
+           _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(counters), _ptr(lr_table), lr_table.numel(), float(beta1), float(beta2),
+           float(eps), _ptr(norm), _ptr(loss_history) if loss_history is not None else None,
+           _ptr(norm_history) if norm_history is not None else None, _ext.stream_ptr(dev))
+    return norm
+
+
 def set_option(dev, name, value):
     _size_cache.clear()
     h = _ext.handle_for(dev)

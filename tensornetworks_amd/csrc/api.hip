@@ -1075,6 +1075,22 @@ int bornvi_clip_cast_grad_guard(bornvi_handle h, int P, const double* grad64, do
   return BORNVI_OK;
 }
 
+int bornvi_clip_adam_step(bornvi_handle h, int P, const double* grad64, double max_norm, const double* loss, float* theta,
+                          float* grad32, double* theta64, float* exp_avg, float* exp_avg_sq, int* counters,
+                          const double* lr_table, int n_lr, double beta1, double beta2, double eps, float* total_norm,
+                          double* loss_history, float* norm_history, bornvi_stream stream) {
+  if (!h) return BORNVI_ERR_INVALID;
+  if (P < 1 || !grad64 || !loss || !theta || !grad32 || !theta64 || !exp_avg || !exp_avg_sq || !counters || !lr_table ||
+      n_lr < 1 || !total_norm || !(max_norm >= 0.0))
+    return fail(h, BORNVI_ERR_INVALID, "bad argument");
+  if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0))
+    return fail(h, BORNVI_ERR_INVALID, "Adam needs 0 <= beta < 1 and eps >= 0");
+  DEVICE_SCOPE(h);
+  HIPCHK(h, launch_clip_adam(grad64, P, max_norm, loss, theta, grad32, theta64, exp_avg, exp_avg_sq, counters, lr_table, n_lr,
+                             beta1, beta2, eps, total_norm, loss_history, norm_history, (hipStream_t)stream));
+  return BORNVI_OK;
+}
+
 size_t bornvi_adjoint_workspace_bytes(bornvi_handle h, int ansatz, int n, int layers) {
   if (!h) return 0;
   AdjPlan* ap = nullptr;

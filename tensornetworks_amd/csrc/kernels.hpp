@@ -52,6 +52,10 @@ hipError_t launch_shift_dot(const double* shifted, int n_shift, const double* w,
                             double* grad, double* loss_out, hipStream_t st);
 hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g32, float* norm_out, const double* loss,
                             float* found_inf, hipStream_t st);
+hipError_t launch_clip_adam(const double* g64, int P, double max_norm, const double* loss, float* theta, float* g32,
+                            double* theta64, float* exp_avg, float* exp_avg_sq, int* counters, const double* lr_table,
+                            int n_lr, double beta1, double beta2, double eps, float* norm_out, double* loss_hist,
+                            float* norm_hist, hipStream_t st);
 hipError_t launch_dldq(const double* y, const double* ksd2, int n, double* dLdq, double* loss_out, hipStream_t st);
 
 // ---- adjoint differentiation (kernels_adjoint.hip): gate-block walks over one / two states ------------

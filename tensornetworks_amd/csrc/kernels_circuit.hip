@@ -1300,6 +1300,79 @@ hipError_t launch_clip_cast(const double* g64, int P, double max_norm, float* g3
   return hipGetLastError();
 }
 
+// The whole optimiser hand-off of one epoch in ONE launch: clip_cast_kernel's norm / clip / NaN-Inf guard followed by the
+// Adam update of torch.optim.Adam (ksd_vi_quantum.py:92-99: no weight decay, no amsgrad) on float32 theta, in the
+// arithmetic of torch's single-kernel implementation (moments and parameter in float32, the products with the double
+// hyper-parameters in double).  For the latency-bound sizes: a replayed step spent 9 of its 15 graph nodes in torch's
+// optimiser, schedule and cast kernels.
+//   counters[0] = good steps so far (the bias corrections' step count; a skipped epoch does not advance it),
+//   counters[1] = epochs so far (indexes lr_table, clamped to its last entry; advances on every call: the reference's
+//                 scheduler steps on a skipped epoch as well, ksd_vi_quantum.py:158-160).
+// loss_hist / norm_hist (or null): the same slot receives the epoch's loss and gradient norm -- the history the
+// reference appends per epoch (:163-166), without a copy launch per epoch.
+// theta64: the float64 copy of the updated theta the next epoch's circuits read (saves the cast launch).
+__global__ __launch_bounds__(256) void clip_adam_kernel(const double* __restrict__ g64, int P, double max_norm,
+                                                        const double* __restrict__ loss, float* __restrict__ theta,
+                                                        float* __restrict__ g32, double* __restrict__ theta64,
+                                                        float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                        int* __restrict__ counters, const double* __restrict__ lr_table,
+                                                        int n_lr, double beta1, double beta2, double eps,
+                                                        float* __restrict__ norm_out, double* __restrict__ loss_hist,
+                                                        float* __restrict__ norm_hist) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < P; i += 256) { const float f = (float)g64[i]; acc += (double)f * (double)f; }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float total = (float)sqrt(red[0]);
+  float coef = (float)max_norm / (total + 1e-6f);
+  if (coef > 1.0f) coef = 1.0f;
+  const double l = *loss;
+  const bool good = (l - l == 0.0);
+  const int step = counters[0] + (good ? 1 : 0), epoch = counters[1];
+  const int slot = epoch < n_lr ? epoch : n_lr - 1;
+  const double lr = lr_table[slot];
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  const float step_size = (float)(lr / (double)bc1);
+  __syncthreads();                       // every thread has read the counters
+  for (int i = threadIdx.x; i < P; i += 256) {
+    const float g = (float)g64[i] * coef;
+    g32[i] = g;
+    float p = theta[i];
+    if (good) {
+      const float m = (float)(beta1 * (double)exp_avg[i] + (1.0 - beta1) * (double)g);
+      const float v = (float)(beta2 * (double)exp_avg_sq[i] + (1.0 - beta2) * (double)g * (double)g);
+      const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + eps);
+      p -= step_size * m / denom;
+      exp_avg[i] = m;
+      exp_avg_sq[i] = v;
+      theta[i] = p;
+    }
+    theta64[i] = (double)p;
+  }
+  if (threadIdx.x == 0) {
+    *norm_out = total;
+    if (loss_hist) loss_hist[slot] = l;          // the epoch's history entries (no copy launches per epoch)
+    if (norm_hist) norm_hist[slot] = total;
+    counters[0] = step;
+    counters[1] = epoch + 1;
+  }
+}
+
+hipError_t launch_clip_adam(const double* g64, int P, double max_norm, const double* loss, float* theta, float* g32,
+                            double* theta64, float* exp_avg, float* exp_avg_sq, int* counters, const double* lr_table,
+                            int n_lr, double beta1, double beta2, double eps, float* norm_out, double* loss_hist,
+                            float* norm_hist, hipStream_t st) {
+  clip_adam_kernel<<<1, 256, 0, st>>>(g64, P, max_norm, loss, theta, g32, theta64, exp_avg, exp_avg_sq, counters, lr_table,
+                                      n_lr, beta1, beta2, eps, norm_out, loss_hist, norm_hist);
+  return hipGetLastError();
+}
+
 // ---- launchers (called from api.hip) --------------------------------------------------------------------
 hipError_t launch_build_gates(const uint32_t* plan, int nfused, const double* thetas, long long theta_stride,
                               int shift_mode, int p_begin, int p_stride, int include_base, long long b_offset, int batch,

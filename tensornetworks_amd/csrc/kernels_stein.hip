@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
       const double* ri0 = Lt + (it * 16 + ar) * g.rowpitch;
       const double* ri1 = ri0 + 16 * g.rowpitch;
       d4_t a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1, c1 = a1, c2 = a1, c3 = a1;
+#ifndef BORNVI_GRAM_NO_MFMA     // (timing-only ablations: tools/probes/build_gram_variants.sh)
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri0[4 * kk + ak], b1[kk], a1, 0, 0, 0);
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
         a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri0[2 * g.p + 4 * kk + ak], b3[kk], a3, 0, 0, 0);
         c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri1[2 * g.p + 4 * kk + ak], b3[kk], c3, 0, 0, 0);
       }
+#else
+      a1[0] = a1[1] = a1[2] = a1[3] = ri0[ak] + b1[0]; c1 = a2 = c2 = a3 = c3 = a1;
+#endif
       // D layout: row = (lane >> 4) + 4 r, col = lane & 15
       const long long ib = i_blk + it * 16 + ak;
       const double* al0 = Lt + (it * 16 + ak) * g.rowpitch + 3 * g.p;   // alpha of row ak + 4 r: + 4 r rowpitch
@@ -263,11 +267,19 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
           e0[r] = al0[4 * r * g.rowpitch] + alpha_j;
           e1[r] = al0[(16 + 4 * r) * g.rowpitch] + alpha_j;
         }
+#ifdef BORNVI_GRAM_NO_STORE
+        double keep = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          keep += w0[r] * ((a1[r] + (a2[r] + a3[r])) + e0[r]) + w1[r] * ((c1[r] + (c2[r] + c3[r])) + e1[r]);
+        if (keep == 1.2345e-300) Kp[0] = keep;
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           __builtin_nontemporal_store(w0[r] * ((a1[r] + (a2[r] + a3[r])) + e0[r]), Kp + (long long)(4 * r) * ld);
           __builtin_nontemporal_store(w1[r] * ((c1[r] + (c2[r] + c3[r])) + e1[r]), Kp + (long long)(16 + 4 * r) * ld);
         }
+#endif
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -59,6 +59,85 @@ class _EventSpan:
         return False
 
 
+def cosine_annealing_lr(epoch, base_lr, T_max, eta_min):
+    """optim.lr_scheduler.CosineAnnealingLR(T_max, eta_min) after `epoch` scheduler steps (scalar or array): its closed
+    form, which its recursive form follows to rounding, beyond T_max as well (both are periodic in 2 T_max)."""
+    e = np.asarray(epoch, dtype=np.float64)
+    v = np.where(e == 0, base_lr, eta_min + (base_lr - eta_min) * (1.0 + np.cos(np.pi * e / T_max)) / 2.0)
+    return v if e.shape else float(v)
+
+
+class DeviceAdam:
+    """optim.Adam(lr, betas) + CosineAnnealingLR(T_max, eta_min) + clip_grad_norm_ + the NaN/Inf guard as ONE launch per
+    epoch (backend.clip_adam_step): moments, step count and epoch count live on the device, the schedule is a table the
+    kernel indexes with its own epoch count.  For the HIP-graph replay of the latency-bound sizes, where torch's fused
+    optimiser, its tensor-valued schedule and the float64 cast of theta were 9 of the step's 15 launches."""
+
+    def __init__(self, theta, lr, betas=(0.9, 0.999), eps=1e-8, T_max=None, eta_min=0.0, capacity=1 << 16):
+        if not (theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous()):
+            raise backend.BornviError("DeviceAdam needs a contiguous float32 theta on the GPU")
+        dev = theta.device
+        self.theta, self.base_lr, self.betas, self.eps = theta, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.T_max, self.eta_min, self.capacity = (None if T_max is None else int(T_max)), float(eta_min), int(capacity)
+        if theta.grad is None:
+            theta.grad = torch.zeros_like(theta)
+        self.exp_avg = torch.zeros(theta.numel(), dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.counters = torch.zeros(2, dtype=torch.int32, device=dev)        # [good steps, epochs since the table's start]
+        self.theta64 = theta.detach().to(torch.float64).clone()              # the circuits' input, kept current by the kernel
+        self.norm = torch.zeros((), dtype=torch.float32, device=dev)
+        self.lr_table = torch.empty(self.capacity, dtype=torch.float64, device=dev)
+        self.loss_hist = torch.zeros(self.capacity, dtype=torch.float64, device=dev)    # written by the kernel, one entry
+        self.norm_hist = torch.zeros(self.capacity, dtype=torch.float32, device=dev)    # per epoch of the window
+        self._hist_done = []                 # (losses, norms) of the windows before the current one
+        self.epochs = 0                      # epochs run so far (host count)
+        self._window = 0                     # epoch of lr_table[0]
+        self._fill()
+
+    def lr_at(self, epoch):
+        """Learning rate of epoch `epoch` (0-based): CosineAnnealingLR's closed form (periodic beyond T_max, like its
+        recursive form), or the constant rate without a schedule."""
+        if self.T_max is None:
+            shape = np.shape(epoch)
+            return np.full(shape, self.base_lr) if shape else self.base_lr
+        return cosine_annealing_lr(epoch, self.base_lr, self.T_max, self.eta_min)
+
+    def _fill(self):
+        vals = self.lr_at(self._window + np.arange(self.capacity))
+        self.lr_table.copy_(torch.from_numpy(np.ascontiguousarray(vals)))
+
+    def step(self, grad64, loss, max_norm):
+        """One epoch's hand-off (enqueued on the current stream; capturable).  -> the gradient norm, a device scalar
+        owned by this object.  Follow it with advance() on the host."""
+        return backend.clip_adam_step(grad64.reshape(-1), max_norm, loss, self.theta.view(-1), self.theta.grad.view(-1),
+                                      self.theta64.view(-1), self.exp_avg, self.exp_avg_sq, self.counters, self.lr_table,
+                                      self.betas[0], self.betas[1], self.eps, norm_out=self.norm,
+                                      loss_history=self.loss_hist, norm_history=self.norm_hist)
+
+    def advance(self):
+        """Host side of an epoch (after step() or a replay of it): counts it, and moves the schedule table on when the
+        device's epoch count is about to run off its end."""
+        self.epochs += 1
+        if self.epochs - self._window >= self.capacity:
+            self._hist_done.append((self.loss_hist.clone(), self.norm_hist.clone()))
+            self._window = self.epochs
+            self._fill()
+            self.counters[1:].zero_()
+
+    def history(self, begin=0, end=None):
+        """(losses float64, gradient norms float32) of epochs [begin, end) as device tensors: what the kernel recorded
+        (the reference's per-epoch loss.item() and clip_grad_norm_ values, ksd_vi_quantum.py:163-166)."""
+        end = self.epochs if end is None else int(end)
+        k = self.epochs - self._window
+        losses = torch.cat([c[0] for c in self._hist_done] + [self.loss_hist[:k]])
+        norms = torch.cat([c[1] for c in self._hist_done] + [self.norm_hist[:k]])
+        return losses[begin:end], norms[begin:end]
+
+    def last_lr(self):
+        """What scheduler.get_last_lr()[0] reads after this many epochs: the rate of the next one."""
+        return self.lr_at(self.epochs)
+
+
 class KSDVariationalInference:
     def __init__(self,
                  bayesian_network,
@@ -544,15 +623,36 @@ class KSDVariationalInference:
             scheduler.step()
         return loss_t, grad_norm, q
 
-    def make_graphed_step(self, params, optimizer_born, scheduler, gradient_clip_norm, warmup=3, record=None):
+    @staticmethod
+    def _device_adam_for(theta, optimizer_born, scheduler):
+        """A DeviceAdam equal to (optimizer_born, scheduler) if they are what make_optimizer builds for "adam" and nothing
+        has stepped yet; None otherwise (the torch objects run the update then)."""
+        if type(optimizer_born) is not optim.Adam or len(optimizer_born.param_groups) != 1 or len(optimizer_born.state) != 0:
+            return None
+        g = optimizer_born.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("differentiable"):
+            return None
+        T_max, eta_min, lr = None, 0.0, float(g["lr"])
+        if scheduler is not None:
+            if type(scheduler) is not optim.lr_scheduler.CosineAnnealingLR or scheduler.last_epoch != 0:
+                return None
+            T_max, eta_min, lr = scheduler.T_max, scheduler.eta_min, float(scheduler.base_lrs[0])
+        return DeviceAdam(theta, lr, g["betas"], g["eps"], T_max, eta_min)
+
+    def make_graphed_step(self, params, optimizer_born, scheduler, gradient_clip_norm, warmup=3, record=None,
+                          device_adam=True):
         """The epoch body of `training_step_async` captured ONCE into a HIP graph (torch.cuda.CUDAGraph: our kernels
         are launched on torch's current stream, so the capture records them together with the cast, the fused Adam
         kernel and the guard) and replayed per step: one graph launch instead of ~15 kernel launches and their host
         work.  For the latency-bound sizes (n <= 13: BASELINE config 2 spends its step in launch overhead, SURVEY
         section 7.4).  Returns step() -> (loss [1], grad_norm, q): tensors OWNED BY THE GRAPH, overwritten by the next
         step (clone what must be kept).  Needs `make_optimizer(..., capturable=True)`; `warmup` eager steps run first
-        (they are real optimiser steps).  The scheduler advances on the host after each replay (it fills the
-        learning-rate tensor the captured Adam kernel reads)."""
+        (they are real optimiser steps).  device_adam (default): clip, guard, Adam, schedule and the float64 cast of
+        theta are one launch of ours (`DeviceAdam`; 6 graph nodes at n = 8 instead of 10 plus 6 eager launches per
+        step) -- equal to torch's update to rounding; the torch optimiser and scheduler objects are then left untouched,
+        `step.adam` is the state and `step.last_lr()` the schedule's rate.  Otherwise (or when the optimiser is not the
+        plain Adam + cosine pair of make_optimizer) torch's capturable fused Adam is captured and the scheduler advances
+        on the host after each replay (it fills the learning-rate tensor the captured Adam kernel reads)."""
         theta = self.born_machine.theta
         if not (theta.is_cuda and theta.dtype == torch.float32 and len(params) == 1 and optimizer_born.defaults.get("capturable")):
             raise backend.BornviError("make_graphed_step needs a float32 theta on the GPU and make_optimizer(capturable=True)")
@@ -562,8 +662,13 @@ class KSDVariationalInference:
         if theta.grad is None:
             theta.grad = torch.zeros_like(theta)
         found = torch.zeros((), dtype=torch.float32, device=dev)
+        adam = self._device_adam_for(theta, optimizer_born, scheduler) if device_adam else None
 
-        def body():
+        def own_body():
+            loss_t, grad64, q = self.ksd_and_grad(theta64=adam.theta64)
+            return loss_t, adam.step(grad64, loss_t, gradient_clip_norm), q
+
+        def torch_body():
             loss_t, grad64, q = self.ksd_and_grad()
             # (the clipped gradient and the guard flag are written straight into theta.grad and the flag tensor the fused
             # Adam kernel reads: no copy nodes in the graph)
@@ -576,6 +681,14 @@ class KSDVariationalInference:
                 del optimizer_born.found_inf
             return loss_t, grad_norm, q
 
+        body = own_body if adam is not None else torch_body
+
+        def host_advance():
+            if adam is not None:
+                adam.advance()
+            elif scheduler is not None:
+                scheduler.step()
+
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -583,8 +696,7 @@ class KSDVariationalInference:
                 w = body()                            # (real optimiser steps: `record`, a list, receives their outputs)
                 if record is not None:
                     record.append(tuple(t.clone() for t in w))
-                if scheduler is not None:
-                    scheduler.step()
+                host_advance()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -593,11 +705,13 @@ class KSDVariationalInference:
 
         def step():
             graph.replay()
-            if scheduler is not None:
-                scheduler.step()
+            host_advance()
             return out
 
         step.graph = graph
+        step.adam = adam
+        step.last_lr = (adam.last_lr if adam is not None else
+                        (lambda: float(scheduler.get_last_lr()[0])) if scheduler is not None else None)
         step.found_inf = found        # the captured kernels write and read this tensor on every replay: it lives as long
         return step                   # as step() does (freed, its block is handed to the caller's next small tensor)
 
@@ -733,11 +847,16 @@ class KSDVariationalInference:
         step = None
         seen = 0                              # epochs whose warnings / values have been reported
 
+        adam = None                           # the graphed step's DeviceAdam: the kernel keeps the history, no clones
+
         def report(upto):
             nonlocal seen
             if upto <= seen:
                 return None
-            vals = torch.stack([l.reshape(()) for l in losses[seen:upto]]).cpu().tolist()
+            if adam is not None:
+                vals = adam.history(seen, upto)[0].cpu().tolist()
+            else:
+                vals = torch.stack([l.reshape(()) for l in losses[seen:upto]]).cpu().tolist()
             for v in vals:
                 if np.isnan(v) or np.isinf(v):
                     print(f"Warning: NaN or Inf KSD loss: {v}. Skipping update.")
@@ -749,16 +868,20 @@ class KSDVariationalInference:
                 rec = []
                 step = self.make_graphed_step(params, optimizer_born, scheduler, gradient_clip_norm, warmup=2, record=rec)
                 pending = rec                 # epochs 0 and 1 are the graph's two eager warm-up steps
+                adam = step.adam
             if use_graph and epoch < 2:
                 loss_t, gn, q = pending[epoch]
+            elif use_graph and adam is not None:
+                loss_t, gn, q = step()        # graph-owned: read below, before the next replay, or not at all
             elif use_graph:
                 loss_t, gn, q = (t.clone() for t in step())
             else:
                 loss_t, gn, q = self.training_step_async(params, optimizer_born, scheduler, gradient_clip_norm)
             if q.shape[0] != self.num_possible_latent_states:
                 raise ValueError(f"Probabilities from Born machine have unexpected shape")
-            losses.append(loss_t)
-            norms.append(gn)
+            if adam is None:
+                losses.append(loss_t)
+                norms.append(gn)
             if tvd_table_dev is not None:     # like the reference: the distribution AFTER this epoch's update (:168)
                 q_now = self.born_machine.get_probabilities().detach().squeeze()
                 tvds.append(tvd_table(tvd_table_dev.to(q_now.device), q_now))
@@ -768,16 +891,22 @@ class KSDVariationalInference:
                 print(f"  Epoch {epoch+1} Grad Norm (after clipping): {float(gn):.4f}")
             if verbose and (epoch % max(1, num_epochs // 20) == 0 or epoch == num_epochs - 1):
                 last = report(epoch + 1)
-                last = float(losses[-1]) if last is None else last
+                last = float(loss_t) if last is None else last
                 log_msg = f"Epoch {epoch+1}/{num_epochs} | KSD: {last:.6f}"
                 if scheduler is not None:
-                    log_msg += f" | LR: {float(scheduler.get_last_lr()[0]):.6f}"
+                    lr_now = (step.adam.lr_at(epoch + 1) if step is not None and step.adam is not None
+                              else float(scheduler.get_last_lr()[0]))
+                    log_msg += f" | LR: {lr_now:.6f}"
                 if tvds:
                     log_msg += f" | TVD: {float(tvds[-1]):.6f}"
                 print(log_msg)
         report(num_epochs)
-        loss_h = torch.stack([l.reshape(()) for l in losses]).cpu().tolist() if losses else []
-        norm_h = torch.stack([g.reshape(()).to(torch.float64) for g in norms]).cpu().tolist() if norms else []
+        if adam is not None:
+            hl, hn = adam.history(0, num_epochs)
+            loss_h, norm_h = hl.cpu().tolist(), hn.to(torch.float64).cpu().tolist()
+        else:
+            loss_h = torch.stack([l.reshape(()) for l in losses]).cpu().tolist() if losses else []
+            norm_h = torch.stack([g.reshape(()).to(torch.float64) for g in norms]).cpu().tolist() if norms else []
         # the reference keeps the last good norm on a skipped epoch (0.0 before the first good one)
         grad_h, last_good = [], None
         for lv, gv in zip(loss_h, norm_h):

@@ -380,13 +380,15 @@ def test_graphed_step_replays_the_async_step(dev):
     n, L = 8, 4
     bn, lat, obs, x = synthetic_network(n, 0)
     runs = []
-    for graphed in (False, True):
+    for graphed in (False, True, "device_adam"):
         vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=21, gram_mode="dense")
         vi._prepare_stein(x)
         params, opt, sched = vi.make_optimizer(0.01, 9, True, "adam", (0.9, 0.999), capturable=True)
         losses = []
         if graphed:
-            step = vi.make_graphed_step(params, opt, sched, 10.0, warmup=3)      # 3 eager steps, then replays
+            step = vi.make_graphed_step(params, opt, sched, 10.0, warmup=3,      # 3 eager steps, then replays
+                                        device_adam=(graphed == "device_adam"))
+            assert (step.adam is not None) == (graphed == "device_adam")
             for _ in range(6):
                 l, gn, q = step()
                 losses.append(float(l))
@@ -396,7 +398,12 @@ def test_graphed_step_replays_the_async_step(dev):
                 l, gn, q = vi.training_step_async(params, opt, sched, 10.0)
                 if i >= 3:
                     losses.append(float(l))
-        runs.append((losses, vi.born_machine.theta.detach().cpu().numpy().copy(), float(sched.get_last_lr()[0])))
+        runs.append((losses, vi.born_machine.theta.detach().cpu().numpy().copy(),
+                     float(step.last_lr()) if graphed else float(sched.get_last_lr()[0])))
+    # the one-launch clip + Adam + schedule (DeviceAdam): the same update to float32 rounding
+    np.testing.assert_allclose(runs[2][0], runs[0][0], rtol=2e-6)
+    np.testing.assert_allclose(runs[2][1], runs[0][1], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(runs[2][2], runs[0][2], rtol=1e-6)
     assert runs[0][0] == runs[1][0]
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
     assert runs[0][2] == runs[1][2]
@@ -406,6 +413,58 @@ def test_graphed_step_replays_the_async_step(dev):
         vi2._prepare_stein(x)
         p2, o2, s2 = vi2.make_optimizer(0.01, 9, True, "adam", (0.9, 0.999))        # not capturable
         vi2.make_graphed_step(p2, o2, s2, 10.0)
+
+
+def test_clip_adam_step_is_torch_adam_behind_the_clip_and_the_guard(dev):
+    """bornvi_clip_adam_step against what it replaces: clip_cast_grad_guard -> torch's fused Adam (found_inf) ->
+    CosineAnnealingLR.step() -> theta.double(), over 12 epochs with a NaN loss and an Inf loss among them (skipped
+    updates; the schedule moves on), a clipped and an unclipped gradient, and a schedule table shorter than the run
+    (refilled on the way).  Moments, theta and norms to float32 rounding, the epoch / step counts exactly."""
+    from tensornetworks_amd import backend
+    from tensornetworks_amd.ksd_vi_quantum import DeviceAdam
+    P, T, lr0 = 37, 7, 0.05
+    g = torch.Generator(device="cpu").manual_seed(5)
+    theta0 = torch.randn(P, generator=g)
+    grads = [torch.randn(P, generator=g, dtype=torch.float64) * (30.0 if e % 3 == 0 else 0.5) for e in range(12)]
+    losses = [float("nan") if e == 4 else float("inf") if e == 9 else 1.0 + e for e in range(12)]
+    # torch
+    th = torch.nn.Parameter(theta0.clone().to(dev))
+    opt = torch.optim.Adam([th], lr=torch.tensor(lr0, device=dev), betas=(0.9, 0.999), fused=True, capturable=True)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=lr0 / 10)
+    ref = []
+    for e in range(12):
+        g32, norm, found = backend.clip_cast_grad_guard(grads[e].to(dev), 10.0, torch.tensor([losses[e]], dtype=torch.float64, device=dev))
+        th.grad = g32
+        opt.found_inf = found
+        opt.step()
+        del opt.found_inf
+        sch.step()
+        ref.append((th.detach().clone(), float(norm)))
+    st = opt.state[th]
+    # ours (a table of 5 entries: refilled twice during the run)
+    th2 = torch.nn.Parameter(theta0.clone().to(dev))
+    adam = DeviceAdam(th2, lr0, (0.9, 0.999), 1e-8, T_max=T, eta_min=lr0 / 10, capacity=5)
+    for e in range(12):
+        norm = adam.step(grads[e].to(dev), torch.tensor([losses[e]], dtype=torch.float64, device=dev), 10.0)
+        adam.advance()
+        np.testing.assert_allclose(th2.detach().cpu().numpy(), ref[e][0].cpu().numpy(), rtol=0, atol=3e-7, err_msg=f"epoch {e}")
+        assert float(norm) == ref[e][1]
+        assert torch.equal(adam.theta64, th2.detach().double())
+        if e in (4, 9):
+            assert torch.equal(th2.detach(), ref[e - 1][0]) or np.allclose(th2.detach().cpu(), ref[e - 1][0].cpu(), atol=3e-7)
+    np.testing.assert_allclose(adam.exp_avg.cpu().numpy(), st["exp_avg"].cpu().numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(adam.exp_avg_sq.cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-12)
+    assert int(adam.counters[0]) == 10 == int(st["step"]) and adam.epochs == 12
+    hl, hn = adam.history()
+    np.testing.assert_array_equal(hl.cpu().numpy(), np.array(losses))
+    assert hn.cpu().tolist() == [r[1] for r in ref]
+    part = adam.history(3, 6)[0].cpu().tolist()
+    assert part[0] == 4.0 and np.isnan(part[1]) and part[2] == 6.0 and len(adam.history(3, 6)[1]) == 3
+    assert abs(adam.last_lr() - float(sch.get_last_lr()[0])) < 1e-7
+    # the clipped gradient is what theta.grad holds
+    np.testing.assert_array_equal(th2.grad.cpu().numpy(), g32.cpu().numpy())
+    with pytest.raises(backend.BornviError):
+        DeviceAdam(torch.zeros(3, dtype=torch.float64, device=dev), 0.1)
 
 
 def test_graphed_step_writes_only_memory_it_owns(dev):

@@ -400,3 +400,22 @@ def test_reinforce_step_against_the_reference_trace():
         loss_q = A._reinforce_loss(log_q, rr)
         assert abs(baseline.item() - g["baseline"][e]) <= 1e-6 * abs(g["baseline"][e])
         assert abs(loss_q.item() - g["loss_q"][e]) <= 1e-6 * max(1.0, abs(g["loss_q"][e])), (e, loss_q.item(), g["loss_q"][e])
+
+
+def test_cosine_schedule_table_follows_torch():
+    """DeviceAdam tabulates CosineAnnealingLR by its closed form: equal to the scheduler's own (recursive) values to
+    rounding, beyond T_max as well (the bench replays more steps than T_max)."""
+    import torch
+    from tensornetworks_amd.ksd_vi_quantum import cosine_annealing_lr
+    for lr0, T, eta in ((0.05, 7, 0.005), (0.005, 1285, 0.0005), (0.1, 1, 0.0)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=lr0)
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=eta)
+        want = [lr0]
+        for _ in range(min(3 * T + 5, 4000)):
+            opt.step()
+            sch.step()
+            want.append(sch.get_last_lr()[0])
+        got = cosine_annealing_lr(np.arange(len(want)), lr0, T, eta)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-15)
+        assert cosine_annealing_lr(0, lr0, T, eta) == lr0
