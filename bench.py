@@ -138,7 +138,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: dense fp64 matrix peak 
 def mfma_extras(vi, dev, n):
     """The two matrix-core kernels of the path, measured live on the trainer's own (padded) K_p: the batched contraction
     Y = K_p Q^T (kernels_batched.hip: v_mfma_f64_16x16x4) for B = 128 and B = 2P + 1 distributions, and the Gram build
-    (kernels_stein.hip: gram_mfma_kernel, rank-3n bilinear form on 16 x 16 tiles; HBM-write bound)."""
+    (kernels_stein.hip: gram_tables_kernel, one MFMA product + two table terms per 16 x 16 tile; HBM-write bound)."""
     from tensornetworks_amd import backend
     N = 1 << n
     out = {}
@@ -172,12 +172,13 @@ def mfma_extras(vi, dev, n):
     ld = int(K.stride(0))
     scratch = torch.empty((N, ld), dtype=torch.float64, device=dev)[:, :N] if ld != N else torch.empty((N, N), dtype=torch.float64, device=dev)
     ms = timed(lambda: backend.stein_gram(vi._S, n, vi.base_kernel_length_scale, out=scratch, ld=ld if ld != N else None))
-    flop = 2.0 * 3 * n * N * N                       # three rank-n products on the matrix cores
-    out["gram_build"] = {"kernel": f"gram_mfma_kernel<{n}>", "ms": round(ms, 3),
+    flop = 2.0 * n * N * N                           # the score product S S^T on the matrix cores (the two bit products: tables)
+    out["gram_build"] = {"kernel": f"gram_tables_kernel<{n}>", "ms": round(ms, 3),
                          "written_gbs": round(8.0 * N * N / (ms * 1e-3) / 1e9, 1),
                          "frac_of_hbm_peak": round(8.0 * N * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "mfma_tflops": round(flop / (ms * 1e-3) / 1e12, 2),
-                         "note": "one-off per observation (outside the step); 8 * 4^n bytes written, 6 n 4^n flop on the matrix cores"}
+                         "note": "one-off per observation (outside the step); 8 * 4^n bytes written, 2 n 4^n flop on the matrix cores "
+                                 "(fp64 MFMA holds the vector ALU on gfx950: the kernel is priced in vector-pipe cycles, DESIGN 4.3)"}
     del scratch
     return out
 

@@ -297,6 +297,232 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
   }
 }
 
+// ---- the shipped form: ONE matrix product per tile, the two bit products from tables ------------------------------
+// Measured on gfx950 (tools/probes/mfma64_probe.hip): v_mfma_f64_16x16x4_f64 holds the SIMD's vector ALU for its 64
+// cycles -- no vector instruction of ANY wave on that SIMD issues beside it (6 MFMAs + 96 v_add_u32 on a second wave
+// take the sum of their times, not the maximum).  So gram_mfma_kernel's time is its 12 MFMAs (768 cycles per tile)
+// PLUS its epilogue (timing-only builds: 6.1 + 3.9 of 10.2 ms at n = 16), software pipelining changes nothing (built,
+// measured, bit-identical, 10.1 ms), and the way down is fewer vector-pipe cycles per tile.  The two products with the
+// 0/1 matrices need no matrix instruction: with the outcome index split into its tile part T (bits >= 4) and its
+// in-tile part c (low 4 bits),
+//     X(z, t) := sum_b G_zb t_b = PH(z, T) + PL(z, c),        G_zb = -dc U_zb,
+// PH(z, T) is one number per (outcome, 16-wide tile of the other index) and PL(z, c) one of 16 per outcome, and
+//     K(i, j) = a^d(i,j) * ( (acc1 + (PL(i, c_j) + PL(j, c_i))) + (A(i, T_j) + A(j, T_i)) ),   A(z, T) = PH(z, T) + alpha_z.
+// Every term is either symmetric in (i, j) or one of a pair added commutatively, and PH / PL / alpha are computed by
+// the same instruction sequence whichever side z is on: K stays BITWISE symmetric.  Per tile: 4 MFMAs (acc1) and
+// ~60 vector instructions instead of 12 and ~75; HBM-write bound from here (8 * 4^n bytes).
+// Workgroup = 4 waves x (64 aligned rows) x GM_COLS columns; rows outside [row_begin, row_end) are computed and not stored.
+template <int n>
+struct GramV3 {
+  static constexpr int NP = (n + 3) / 4 * 4;            // scores padded to the MFMA's k = 4
+  static constexpr int KK = NP / 4;
+  static constexpr int NH = n - 4;                      // tile bits of an outcome index
+  static constexpr int OFF_G = NP;                      // row layout in LDS: F1 (MFMA order) | G high | PL table | alpha
+  static constexpr int OFF_PL = OFF_G + NH;
+  static constexpr int OFF_AL = OFF_PL + 16;
+  static constexpr int PITCH = ((OFF_AL + 1 + 3) / 4) * 4 + 2;      // = 2 (mod 4): 16 rows x 16-byte reads spread over the banks
+};
+
+// alpha_z and G_zb of one outcome from its scores (the same code on the row side and on the column side)
+template <int n>
+__device__ __forceinline__ void gram_v3_outcome(const double (&sv)[GM_MAXN], long long z, double c_same, double dc,
+                                                double (&G)[GM_MAXN], double& alpha) {
+  // (no fused multiply-adds the source does not spell out, here and in the two sums below: a multiplier that is a
+  // compile-time 1.0 on one side turns fma(G, 1, acc) into acc + G, and contracting THAT with G's own product would
+  // skip a rounding the other side performs -- K would lose its bitwise symmetry)
+#pragma clang fp contract(off)
+  double rt = 0.0, ab = 0.0;
+#pragma unroll
+  for (int b = 0; b < n; ++b) {
+    const double t = sv[b] - 1.0;
+    const bool bit = (z >> (n - 1 - b)) & 1ll;
+    rt += t;
+    ab += bit ? t : 0.0;
+    G[b] = (bit ? dc : -dc) * t;
+  }
+  alpha = __builtin_fma(-dc, ab, -c_same * rt);      // (spelled out: both sides must round alike)
+}
+
+// G and alpha of every outcome, once per build ([2^n][n + 1] doubles: G_z0 .. G_z,n-1, alpha_z): both sides of the
+// main kernel read them from here (a wave would otherwise redo them for its 16 columns at every column tile: a third
+// of its vector instructions)
+template <int n>
+__global__ __launch_bounds__(256) void gram_prep_kernel(const double* __restrict__ S, double c_same, double dc,
+                                                       double* __restrict__ GA) {
+  const long long z = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (z >= (1ll << n)) return;
+  double sv[GM_MAXN], G[GM_MAXN], alpha;
+  gram_load_scores<n>(S, z, sv);
+  gram_v3_outcome<n>(sv, z, c_same, dc, G, alpha);
+#pragma unroll
+  for (int b = 0; b < n; ++b) GA[z * (n + 1) + b] = G[b];
+  GA[z * (n + 1) + n] = alpha;
+}
+
+template <int n>
+__device__ __forceinline__ void gram_load_ga(const double* __restrict__ GA, long long z, double (&G)[GM_MAXN], double& alpha) {
+#pragma unroll
+  for (int b = 0; b < GM_MAXN; ++b) G[b] = (b < n) ? GA[z * (n + 1) + b] : 0.0;
+  alpha = GA[z * (n + 1) + n];
+}
+
+// PH(z, T): the tile bits of the other index, most significant first; m = 1.0 / 0.0 per bit (one fma per bit on both sides)
+template <int n, int FIRST, int LAST>
+__device__ __forceinline__ double gram_v3_ph(const double (&G)[GM_MAXN], long long T, double acc) {
+#pragma clang fp contract(off)
+  constexpr int NH = n - 4;
+#pragma unroll
+  for (int b = FIRST; b < LAST; ++b) acc = __builtin_fma(G[b], ((T >> (NH - 1 - b)) & 1ll) ? 1.0 : 0.0, acc);
+  return acc;
+}
+
+// PL(z, c): the in-tile bits, most significant first
+template <int n>
+__device__ __forceinline__ double gram_v3_pl(const double (&G)[GM_MAXN], double m3, double m2, double m1, double m0) {
+#pragma clang fp contract(off)
+  double acc = __builtin_fma(G[n - 4], m3, 0.0);
+  acc = __builtin_fma(G[n - 3], m2, acc);
+  acc = __builtin_fma(G[n - 2], m1, acc);
+  return __builtin_fma(G[n - 1], m0, acc);
+}
+
+// the walk of one wave over its column tiles (GUARD: the block sticks out of [row_begin, row_end): per-row store tests)
+template <int n, bool GUARD>
+__device__ __forceinline__ void gram_tables_columns(const double* __restrict__ S, const double* __restrict__ GA,
+                                                    const double* __restrict__ Lt, double* __restrict__ AJ,
+                                                    const double* __restrict__ apow_s, const double (&Gh)[GM_MAXN], double alpha_row,
+                                                    int aj_slot, const double (&PLr)[GM_ROWS / 16][4], const int (&wslot)[4],
+                                                    double mk1, double mk0, unsigned voff, long long i_blk, long long I0,
+                                                    double* __restrict__ Kblk, long long ld, long long j0, long long j_chunk_end,
+                                                    double c_same, double dc, long long row_begin, long long row_end, int ar, int ak) {
+  using L = GramV3<n>;
+  constexpr int KK = L::KK, NH = L::NH, PITCH = L::PITCH;
+  // two register sets for the column factors: a tile works on one while the next tile's loads land in the other (a
+  // single set rotated through copies cost 44 register moves per column tile)
+  double Ga[GM_MAXN], Gb[GM_MAXN], alpha_a, alpha_b, ba[KK], bb[KK];
+  auto fetch = [&](long long jt, double (&G)[GM_MAXN], double& alpha, double (&bf)[KK]) {
+    gram_load_ga<n>(GA, jt + ar, G, alpha);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) bf[kk] = (4 * kk + ak < n) ? S[(jt + ar) * n + 4 * kk + ak] : 0.0;
+  };
+  auto tile_column = [&](long long jt, const double (&G)[GM_MAXN], double alpha_j, const double (&b1)[KK]) {
+    const long long J = jt >> 4;
+    // column side: A(j, I) for the block's four row tiles (they share all but the last two tile bits), PL(j, c_i)
+    const double ph_hi = gram_v3_ph<n, 0, NH - 2>(G, I0, 0.0);
+    double Bj[GM_ROWS / 16], PLc[4];
+#pragma unroll
+    for (int rt = 0; rt < GM_ROWS / 16; ++rt) Bj[rt] = gram_v3_ph<n, NH - 2, NH>(G, I0 + rt, ph_hi) + alpha_j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) PLc[r] = gram_v3_pl<n>(G, (r & 2) ? 1.0 : 0.0, (r & 1) ? 1.0 : 0.0, mk1, mk0);
+    // row side: A(row, J) of the lane's own row, handed to the lanes that need it through the wave's scratch
+    AJ[aj_slot] = gram_v3_ph<n, 0, NH>(Gh, J, 0.0) + alpha_row;
+    __builtin_amdgcn_wave_barrier();
+    double* __restrict__ Kc = Kblk + jt;
+#pragma unroll
+    for (int rt = 0; rt < GM_ROWS / 16; ++rt) {
+      const double* ri = Lt + (rt * 16 + ar) * PITCH + ak * KK;
+      d4_t a1 = {0.0, 0.0, 0.0, 0.0};
+#ifndef BORNVI_GRAM_NO_MFMA
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ri[kk], b1[kk], a1, 0, 0, 0);
+#else
+      a1[0] = a1[1] = a1[2] = a1[3] = ri[0] + b1[0];
+#endif
+      const double* aj = AJ + rt * 16 + ak * 4;
+      const double* wt = apow_s + __popcll((unsigned long long)((I0 + rt) ^ J));
+      double* __restrict__ rowp = Kc + (long long)(rt * 16) * ld;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double val = wt[wslot[r]] * ((a1[r] + (PLr[rt][r] + PLc[r])) + (aj[r] + Bj[rt]));
+        const long long i = i_blk + rt * 16 + ak + 4 * r;
+#ifdef BORNVI_GRAM_NO_STORE      // (timing-only ablation: tools/probes/build_gram_variants.sh)
+        if (val == 1.2345e-300)
+#else
+        if (!GUARD || (i >= row_begin && i < row_end))
+#endif
+          __builtin_nontemporal_store(val, reinterpret_cast<double*>(reinterpret_cast<char*>(rowp + (long long)(4 * r) * ld) + voff));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();     // the scratch is rewritten by the next column tile
+  };
+  fetch(j0, Ga, alpha_a, ba);
+#pragma unroll 1
+  for (;;) {
+    if (j0 + 64 < j_chunk_end) fetch(j0 + 64, Gb, alpha_b, bb);
+    tile_column(j0, Ga, alpha_a, ba);
+    j0 += 64;
+    if (j0 >= j_chunk_end) break;
+    if (j0 + 64 < j_chunk_end) fetch(j0 + 64, Ga, alpha_a, ba);
+    tile_column(j0, Gb, alpha_b, bb);
+    j0 += 64;
+    if (j0 >= j_chunk_end) break;
+  }
+}
+
+template <int n>
+__global__ __launch_bounds__(256, 2) void gram_tables_kernel(const double* __restrict__ S, double* __restrict__ K,
+                                                            const double* __restrict__ GA, PowTable apow, double c_same,
+                                                            double dc, long long row_begin, long long row_end, long long ld) {
+  using L = GramV3<n>;
+  extern __shared__ double gm_lds[];
+  __shared__ double apow_s[40];
+  constexpr int KK = L::KK, NH = L::NH, PITCH = L::PITCH;
+  const long long N = 1ll << n;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double* __restrict__ Lt = gm_lds;                                   // [GM_ROWS][PITCH]
+  double* __restrict__ AJ = gm_lds + GM_ROWS * PITCH + wave * GM_ROWS;   // this wave's A(row, J), in [row tile][ak][r] order
+  if (threadIdx.x < 40) apow_s[threadIdx.x] = threadIdx.x < 33 ? apow.v[threadIdx.x] : 0.0;
+  const long long i_blk = (row_begin & ~(long long)(GM_ROWS - 1)) + (long long)blockIdx.y * GM_ROWS;   // 64-aligned
+  if (threadIdx.x < GM_ROWS) {
+    const long long i = i_blk + threadIdx.x;
+    double sv[GM_MAXN], G[GM_MAXN], alpha;
+    gram_load_scores<n>(S, i, sv);
+    gram_load_ga<n>(GA, i, G, alpha);
+    double* r = Lt + threadIdx.x * PITCH;
+#pragma unroll
+    for (int b = 0; b < L::NP; ++b) r[(b & 3) * KK + (b >> 2)] = (b < n) ? sv[b] : 0.0;    // lane ak reads its KK values in one go
+#pragma unroll
+    for (int b = 0; b < NH; ++b) r[L::OFF_G + b] = G[b];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      r[L::OFF_PL + c] = gram_v3_pl<n>(G, (c & 8) ? 1.0 : 0.0, (c & 4) ? 1.0 : 0.0, (c & 2) ? 1.0 : 0.0, (c & 1) ? 1.0 : 0.0);
+    r[L::OFF_AL] = alpha;
+  }
+  __syncthreads();
+  const long long j_chunk = (long long)blockIdx.x * GM_COLS;
+  const long long j_chunk_end = (j_chunk + GM_COLS < N) ? j_chunk + GM_COLS : N;
+  long long j0 = j_chunk + wave * 16;
+  if (j0 >= j_chunk_end) return;
+  const int ar = lane & 15, ak = lane >> 4;
+  // loop-invariant per lane: this lane's row (lane = row of the block) for A(row, J); PL(i, c = ar) of its 16 outputs' rows
+  double Gh[GM_MAXN];
+#pragma unroll
+  for (int b = 0; b < GM_MAXN; ++b) Gh[b] = (b < NH) ? Lt[lane * PITCH + L::OFF_G + b] : 0.0;
+  const double alpha_row = Lt[lane * PITCH + L::OFF_AL];
+  const int aj_slot = (lane & 48) | ((lane & 3) << 2) | ((lane >> 2) & 3);     // row rt*16 + 4r + ak -> [rt][ak][r]
+  double PLr[GM_ROWS / 16][4];
+#pragma unroll
+  for (int rt = 0; rt < GM_ROWS / 16; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) PLr[rt][r] = Lt[(rt * 16 + ak + 4 * r) * PITCH + L::OFF_PL + ar];
+  int wslot[4];                                         // a^d table: popcount of the in-tile bits of i ^ j
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wslot[r] = __popc((unsigned)((ak + 4 * r) ^ ar));
+  const double mk1 = (ak & 2) ? 1.0 : 0.0, mk0 = (ak & 1) ? 1.0 : 0.0;     // low bits of this lane's rows ak + 4 r
+  const unsigned voff = (unsigned)(((long long)ak * ld + ar) * 8);
+  const bool whole = i_blk >= row_begin && i_blk + GM_ROWS <= row_end;      // (uniform) no per-row tests
+  const long long I0 = i_blk >> 4;                     // tile index of row tile 0
+  double* __restrict__ Kblk = K + (i_blk - row_begin) * ld;                 // (not dereferenced for rows outside the range)
+
+  if (whole)
+    gram_tables_columns<n, false>(S, GA, Lt, AJ, apow_s, Gh, alpha_row, aj_slot, PLr, wslot, mk1, mk0, voff, i_blk, I0, Kblk, ld, j0,
+                                  j_chunk_end, c_same, dc, row_begin, row_end, ar, ak);
+  else
+    gram_tables_columns<n, true>(S, GA, Lt, AJ, apow_s, Gh, alpha_row, aj_slot, PLr, wslot, mk1, mk0, voff, i_blk, I0, Kblk, ld, j0,
+                                 j_chunk_end, c_same, dc, row_begin, row_end, ar, ak);
+}
+
 template <int NB>
 static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable& apow, double c_same, double dc,
                                       long long row_begin, long long row_end, long long ld, hipStream_t st) {
@@ -309,6 +535,24 @@ static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable
     if (e != hipSuccess) return e;
   }
   const long long cols = N < GM_COLS ? N : GM_COLS;
+  // BORNVI_GRAM_TABLES=0: the three-product kernel (A/B; one process builds every matrix with one of the two -- their
+  // roundings differ, and K's two triangles must come from the same arithmetic)
+  static const bool tables = [] { const char* e = getenv("BORNVI_GRAM_TABLES"); return !(e && e[0] == '0'); }();
+  if (tables) {
+    const size_t lds3 = (size_t)(GM_ROWS * GramV3<NB>::PITCH + 4 * GM_ROWS) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tables_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e != hipSuccess) return e;
+    const long long first = row_begin & ~(long long)(GM_ROWS - 1);
+    dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - first + GM_ROWS - 1) / GM_ROWS));
+    double* GA = nullptr;                 // stream-ordered scratch: (n + 1) 2^n doubles (8.9 MB at n = 16)
+    e = hipMallocAsync((void**)&GA, (size_t)(NB + 1) * (size_t)N * sizeof(double), st);
+    if (e != hipSuccess) return e;
+    gram_prep_kernel<NB><<<(unsigned)((N + 255) / 256), 256, 0, st>>>(S, c_same, dc, GA);
+    gram_tables_kernel<NB><<<grid, 256, lds3, st>>>(S, K, GA, apow, c_same, dc, row_begin, row_end, ld);
+    e = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(GA, st);
+    return e != hipSuccess ? e : e2;
+  }
   dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - row_begin + GM_ROWS - 1) / GM_ROWS));
   gram_mfma_kernel<NB><<<grid, 256, lds, st>>>(S, K, apow, c_same, dc, row_begin, row_end, ld);
   return hipGetLastError();

@@ -1,5 +1,6 @@
 set -e
-for v in shipped nomfma nostore neither; do
-  if [ $v = shipped ]; then unset BORNVI_LIB; else export BORNVI_LIB=$PWD/tools/_variants/libbornvi_gram_$v.so; fi
-  timeout -k 10 120 python tools/probes/gram_probe.py 16 5
+for n in 16 13 8; do
+for t in 0 1; do
+  BORNVI_GRAM_TABLES=$t timeout -k 10 120 python tools/probes/gram_probe.py $n 5
+done
 done

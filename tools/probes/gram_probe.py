@@ -25,7 +25,10 @@ def timed(fn):
 
 backend.stein_gram(S, n, 1.0, out=K); torch.cuda.synchronize()
 t = timed(lambda: backend.stein_gram(S, n, 1.0, out=K))
+import hashlib
+digest = hashlib.sha256(K[:, :].contiguous().cpu().numpy().tobytes()).hexdigest()[:16] if n <= 14 else hashlib.sha256(K[:2048].contiguous().cpu().numpy().tobytes() + K[N - 2048:].contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+sym = bool(torch.equal(K[:4096, :4096], K[:4096, :4096].T)) and bool(torch.equal(K[:1024, N - 1024:], K[N - 1024:, :1024].T))
 f = timed(lambda: buf.fill_(1.0))
 gb = N * N * 8 / 1e9
-print(f"lib={os.environ.get('BORNVI_LIB', 'shipped')} n={n} ld={ld} gram ms {[round(x, 3) for x in t]} -> {gb / min(t):.0f} GB/s"
-      f" | fill ms {[round(x, 3) for x in f]} -> {N * ld * 8 / 1e9 / min(f):.0f} GB/s | sym {bool(torch.equal(K[:4096, :4096], K[:4096, :4096].T))}")
+print(f"lib={os.environ.get('BORNVI_LIB', 'shipped')} n={n} ld={ld} gram ms {[round(x, 3) for x in t]} -> {gb / min(t) * 1e3:.0f} GB/s"
+      f" | digest {digest} tables={os.environ.get('BORNVI_GRAM_TABLES', '1')} | fill ms {[round(x, 3) for x in f]} -> {N * ld * 8 / 1e9 / min(f) * 1e3:.0f} GB/s | sym {sym}")
