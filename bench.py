@@ -378,7 +378,7 @@ def measure(workload, dev, D, args, steps, warmup, repeats, want_extras):
     losses = []
     if use_graph:
         # latency-bound sizes: the whole step (circuits, contraction, gradient, clip, Adam) replayed from ONE HIP graph
-        graphed = vi.make_graphed_step(*opt_state, clip, warmup=max(3, warmup))
+        graphed = vi.make_graphed_step(*opt_state, clip, warmup=max(3, warmup), device_adam=args.device_adam != 0)
         if graphed.adam is not None:      # the optimiser kernel records every epoch's loss on the device: nothing to clone
             step_fn = lambda params, opt, sched, clip_: graphed()
         else:
@@ -713,6 +713,7 @@ def main(argv=None):
     ap.add_argument("--overlap", type=int, default=0,
                     help="how circuits and contraction share the GPU: 0 in sequence (default), 1 second plain stream, 2 two "
                          "CU-masked streams (half the CUs each), -1 measured choice between 0 and 2 (choose_overlap)")
+    ap.add_argument("--device-adam", type=int, default=1, help="graph replay: 0 = torch's capturable Adam + scheduler (A/B)")
     ap.add_argument("--no-dist-selftest", action="store_true", help="N > 1: skip the sharded-vs-unsharded check (on by default)")
     args = ap.parse_args(argv)
 
