@@ -520,6 +520,24 @@ def test_train_without_host_sync_returns_the_same_history(dev, n, L, opt, with_t
     assert h1["loss_ksd"][-1] < h1["loss_ksd"][0]
 
 
+def test_train_without_host_sync_and_without_a_schedule(dev, capsys):
+    """use_lr_scheduler=False through the graph-replayed path: DeviceAdam runs with a constant rate (a one-value table) --
+    the same history as the reference-style loop, no LR in the log lines."""
+    n, L = 8, 1
+    bn, lat, obs, x = synthetic_network(n, 2)
+    runs = []
+    for host_sync in (True, False):
+        vi = make_vi(bn, lat, obs, n, L, "hardware_efficient", "cuda:0", seed=9, gram_mode="dense")
+        h = vi.train(x, 8, 0.02, verbose=True, use_lr_scheduler=False, host_sync=host_sync)
+        out = capsys.readouterr().out
+        runs.append((h, vi.born_machine.theta.detach().cpu().numpy().copy(), [l for l in out.splitlines() if l.startswith("Epoch ")]))
+    (h0, t0, log0), (h1, t1, log1) = runs
+    np.testing.assert_allclose(h1["loss_ksd"], h0["loss_ksd"], rtol=2e-5)
+    np.testing.assert_allclose(h1["grad_norm"], [float(g) for g in h0["grad_norm"]], rtol=2e-4)
+    np.testing.assert_allclose(t1, t0, rtol=0, atol=2e-5)
+    assert log0 and len(log1) == len(log0) and not any("LR:" in l for l in log0 + log1)
+
+
 def test_second_train_keeps_the_gram_matrix_unless_the_scores_change(dev, capsys):
     """K_p depends on (S, n, length scale) only: a second _prepare_stein / train() on the same observation keeps the matrix
     (at n = 16 that is 32 GiB and a placement search); another observation, length scale or contraction layout rebuilds."""
