@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include <cmath>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -386,17 +387,20 @@ __device__ __forceinline__ double gram_v3_pl(const double (&G)[GM_MAXN], double 
   return __builtin_fma(G[n - 1], m0, acc);
 }
 
-// the walk of one wave over its column tiles (GUARD: the block sticks out of [row_begin, row_end): per-row store tests)
-template <int n, bool GUARD>
+// the walk of one wave over its column tiles (R rows per workgroup; GUARD: the block sticks out of [row_begin, row_end):
+// per-row store tests)
+template <int n, int R, bool GUARD>
 __device__ __forceinline__ void gram_tables_columns(const double* __restrict__ S, const double* __restrict__ GA,
-                                                    const double* __restrict__ Lt, double* __restrict__ AJ,
-                                                    const double* __restrict__ apow_s, const double (&Gh)[GM_MAXN], double alpha_row,
-                                                    int aj_slot, const double (&PLr)[GM_ROWS / 16][4], const int (&wslot)[4],
+                                                    const double* __restrict__ Lt_, double* __restrict__ AJ,
+                                                    const double* __restrict__ apow_s, int lane, const int (&wslot)[4],
                                                     double mk1, double mk0, unsigned voff, long long i_blk, long long I0,
                                                     double* __restrict__ Kblk, long long ld, long long j0, long long j_chunk_end,
-                                                    double c_same, double dc, long long row_begin, long long row_end, int ar, int ak) {
+                                                    long long row_begin, long long row_end, int ar, int ak) {
   using L = GramV3<n>;
   constexpr int KK = L::KK, NH = L::NH, PITCH = L::PITCH;
+  constexpr int RT = R / 16;                            // row tiles of the block
+  constexpr int NV = RT == 8 ? 3 : (RT == 4 ? 2 : 1);   // tile bits that differ between them
+  static_assert(RT == 8 || RT == 4, "64 or 128 rows per workgroup");
   // two register sets for the column factors: a tile works on one while the next tile's loads land in the other (a
   // single set rotated through copies cost 44 register moves per column tile)
   double Ga[GM_MAXN], Gb[GM_MAXN], alpha_a, alpha_b, ba[KK], bb[KK];
@@ -407,19 +411,34 @@ __device__ __forceinline__ void gram_tables_columns(const double* __restrict__ S
   };
   auto tile_column = [&](long long jt, const double (&G)[GM_MAXN], double alpha_j, const double (&b1)[KK]) {
     const long long J = jt >> 4;
-    // column side: A(j, I) for the block's four row tiles (they share all but the last two tile bits), PL(j, c_i)
-    const double ph_hi = gram_v3_ph<n, 0, NH - 2>(G, I0, 0.0);
-    double Bj[GM_ROWS / 16], PLc[4];
-#pragma unroll
-    for (int rt = 0; rt < GM_ROWS / 16; ++rt) Bj[rt] = gram_v3_ph<n, NH - 2, NH>(G, I0 + rt, ph_hi) + alpha_j;
+    // (the row block's LDS image through an offset the compiler cannot see through: its loop-invariant reads -- 16 to 32 A
+    // fragments, as many PL values -- are re-read per column tile instead of being hoisted into 100+ registers)
+    int opaque0 = 0;
+    asm volatile("" : "+v"(opaque0));
+    const double* __restrict__ Lt = Lt_ + opaque0;
+    // column side: A(j, I) for the block's row tiles (they share all but the last NV tile bits), PL(j, c_i)
+    const double ph_hi = gram_v3_ph<n, 0, NH - NV>(G, I0, 0.0);
+    double PLc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) PLc[r] = gram_v3_pl<n>(G, (r & 2) ? 1.0 : 0.0, (r & 1) ? 1.0 : 0.0, mk1, mk0);
-    // row side: A(row, J) of the lane's own row, handed to the lanes that need it through the wave's scratch
-    AJ[aj_slot] = gram_v3_ph<n, 0, NH>(Gh, J, 0.0) + alpha_row;
+    // row side: A(row, J) of the lane's own rows (lane, lane + 64, ...: their G from LDS), handed to the lanes that need
+    // them through the wave's scratch
+#pragma unroll
+    for (int h = 0; h < R / 64; ++h) {
+      const int row = lane + 64 * h;
+      const double* gr = Lt + row * PITCH + L::OFF_G;
+      double Gr[GM_MAXN];
+#pragma unroll
+      for (int b = 0; b < GM_MAXN; ++b) Gr[b] = (b < NH) ? gr[b] : 0.0;
+      AJ[(row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3)] = gram_v3_ph<n, 0, NH>(Gr, J, 0.0) + gr[L::OFF_AL - L::OFF_G];
+    }
     __builtin_amdgcn_wave_barrier();
     double* __restrict__ Kc = Kblk + jt;
-#pragma unroll
-    for (int rt = 0; rt < GM_ROWS / 16; ++rt) {
+    // (one row tile per trip, not unrolled: eight tiles' worth of hoisted LDS reads do not fit the 256 registers of two waves
+    // per SIMD, and a tile's MFMAs cannot overlap another tile's vector work anyway -- same pipe)
+#pragma unroll 1
+    for (int rt = 0; rt < RT; ++rt) {
+      const double Bj_rt = gram_v3_ph<n, NH - NV, NH>(G, I0 + rt, ph_hi) + alpha_j;
       const double* ri = Lt + (rt * 16 + ar) * PITCH + ak * KK;
       d4_t a1 = {0.0, 0.0, 0.0, 0.0};
 #ifndef BORNVI_GRAM_NO_MFMA
@@ -429,11 +448,12 @@ __device__ __forceinline__ void gram_tables_columns(const double* __restrict__ S
       a1[0] = a1[1] = a1[2] = a1[3] = ri[0] + b1[0];
 #endif
       const double* aj = AJ + rt * 16 + ak * 4;
+      const double* plr = Lt + (rt * 16 + ak) * PITCH + L::OFF_PL + ar;      // PL(row ak + 4 r of the tile, c = ar)
       const double* wt = apow_s + __popcll((unsigned long long)((I0 + rt) ^ J));
       double* __restrict__ rowp = Kc + (long long)(rt * 16) * ld;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double val = wt[wslot[r]] * ((a1[r] + (PLr[rt][r] + PLc[r])) + (aj[r] + Bj[rt]));
+        const double val = wt[wslot[r]] * ((a1[r] + (plr[4 * r * PITCH] + PLc[r])) + (aj[r] + Bj_rt));
         const long long i = i_blk + rt * 16 + ak + 4 * r;
 #ifdef BORNVI_GRAM_NO_STORE      // (timing-only ablation: tools/probes/build_gram_variants.sh)
         if (val == 1.2345e-300)
@@ -459,7 +479,7 @@ __device__ __forceinline__ void gram_tables_columns(const double* __restrict__ S
   }
 }
 
-template <int n>
+template <int n, int R>
 __global__ __launch_bounds__(256, 2) void gram_tables_kernel(const double* __restrict__ S, double* __restrict__ K,
                                                             const double* __restrict__ GA, PowTable apow, double c_same,
                                                             double dc, long long row_begin, long long row_end, long long ld) {
@@ -470,11 +490,11 @@ __global__ __launch_bounds__(256, 2) void gram_tables_kernel(const double* __res
   const long long N = 1ll << n;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  double* __restrict__ Lt = gm_lds;                                   // [GM_ROWS][PITCH]
-  double* __restrict__ AJ = gm_lds + GM_ROWS * PITCH + wave * GM_ROWS;   // this wave's A(row, J), in [row tile][ak][r] order
+  double* __restrict__ Lt = gm_lds;                        // [R][PITCH]
+  double* __restrict__ AJ = gm_lds + R * PITCH + wave * R;   // this wave's A(row, J), in [row tile][ak][r] order
   if (threadIdx.x < 40) apow_s[threadIdx.x] = threadIdx.x < 33 ? apow.v[threadIdx.x] : 0.0;
-  const long long i_blk = (row_begin & ~(long long)(GM_ROWS - 1)) + (long long)blockIdx.y * GM_ROWS;   // 64-aligned
-  if (threadIdx.x < GM_ROWS) {
+  const long long i_blk = (row_begin & ~(long long)(R - 1)) + (long long)blockIdx.y * R;   // R-aligned
+  if (threadIdx.x < R) {
     const long long i = i_blk + threadIdx.x;
     double sv[GM_MAXN], G[GM_MAXN], alpha;
     gram_load_scores<n>(S, i, sv);
@@ -495,32 +515,20 @@ __global__ __launch_bounds__(256, 2) void gram_tables_kernel(const double* __res
   long long j0 = j_chunk + wave * 16;
   if (j0 >= j_chunk_end) return;
   const int ar = lane & 15, ak = lane >> 4;
-  // loop-invariant per lane: this lane's row (lane = row of the block) for A(row, J); PL(i, c = ar) of its 16 outputs' rows
-  double Gh[GM_MAXN];
-#pragma unroll
-  for (int b = 0; b < GM_MAXN; ++b) Gh[b] = (b < NH) ? Lt[lane * PITCH + L::OFF_G + b] : 0.0;
-  const double alpha_row = Lt[lane * PITCH + L::OFF_AL];
-  const int aj_slot = (lane & 48) | ((lane & 3) << 2) | ((lane >> 2) & 3);     // row rt*16 + 4r + ak -> [rt][ak][r]
-  double PLr[GM_ROWS / 16][4];
-#pragma unroll
-  for (int rt = 0; rt < GM_ROWS / 16; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) PLr[rt][r] = Lt[(rt * 16 + ak + 4 * r) * PITCH + L::OFF_PL + ar];
   int wslot[4];                                         // a^d table: popcount of the in-tile bits of i ^ j
 #pragma unroll
   for (int r = 0; r < 4; ++r) wslot[r] = __popc((unsigned)((ak + 4 * r) ^ ar));
   const double mk1 = (ak & 2) ? 1.0 : 0.0, mk0 = (ak & 1) ? 1.0 : 0.0;     // low bits of this lane's rows ak + 4 r
   const unsigned voff = (unsigned)(((long long)ak * ld + ar) * 8);
-  const bool whole = i_blk >= row_begin && i_blk + GM_ROWS <= row_end;      // (uniform) no per-row tests
+  const bool whole = i_blk >= row_begin && i_blk + R <= row_end;            // (uniform) no per-row tests
   const long long I0 = i_blk >> 4;                     // tile index of row tile 0
   double* __restrict__ Kblk = K + (i_blk - row_begin) * ld;                 // (not dereferenced for rows outside the range)
-
   if (whole)
-    gram_tables_columns<n, false>(S, GA, Lt, AJ, apow_s, Gh, alpha_row, aj_slot, PLr, wslot, mk1, mk0, voff, i_blk, I0, Kblk, ld, j0,
-                                  j_chunk_end, c_same, dc, row_begin, row_end, ar, ak);
+    gram_tables_columns<n, R, false>(S, GA, Lt, AJ, apow_s, lane, wslot, mk1, mk0, voff, i_blk, I0, Kblk, ld, j0, j_chunk_end,
+                                     row_begin, row_end, ar, ak);
   else
-    gram_tables_columns<n, true>(S, GA, Lt, AJ, apow_s, Gh, alpha_row, aj_slot, PLr, wslot, mk1, mk0, voff, i_blk, I0, Kblk, ld, j0,
-                                 j_chunk_end, c_same, dc, row_begin, row_end, ar, ak);
+    gram_tables_columns<n, R, true>(S, GA, Lt, AJ, apow_s, lane, wslot, mk1, mk0, voff, i_blk, I0, Kblk, ld, j0, j_chunk_end,
+                                    row_begin, row_end, ar, ak);
 }
 
 template <int NB>
@@ -539,17 +547,25 @@ static hipError_t launch_gram_mfma_nb(const double* S, double* K, const PowTable
   // roundings differ, and K's two triangles must come from the same arithmetic)
   static const bool tables = [] { const char* e = getenv("BORNVI_GRAM_TABLES"); return !(e && e[0] == '0'); }();
   if (tables) {
-    const size_t lds3 = (size_t)(GM_ROWS * GramV3<NB>::PITCH + 4 * GM_ROWS) * sizeof(double);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tables_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    if (e != hipSuccess) return e;
-    const long long first = row_begin & ~(long long)(GM_ROWS - 1);
-    dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - first + GM_ROWS - 1) / GM_ROWS));
+    // rows per workgroup: 64.  128 (BORNVI_GRAM_ROWS=128, A/B) halves the column side's work per tile and measures the
+    // same at n = 16 (6.9 ms both: with the tables the kernel waits for its stores -- 6.9 ms without the MFMAs too, 6.1 ms
+    // without the stores) and slower for small matrices (n = 9: 47 against 37 us)
+    static const bool rows64 = [] { const char* e = getenv("BORNVI_GRAM_ROWS"); return !(e && e[0] == '1'); }();
     double* GA = nullptr;                 // stream-ordered scratch: (n + 1) 2^n doubles (8.9 MB at n = 16)
-    e = hipMallocAsync((void**)&GA, (size_t)(NB + 1) * (size_t)N * sizeof(double), st);
+    hipError_t e = hipMallocAsync((void**)&GA, (size_t)(NB + 1) * (size_t)N * sizeof(double), st);
     if (e != hipSuccess) return e;
     gram_prep_kernel<NB><<<(unsigned)((N + 255) / 256), 256, 0, st>>>(S, c_same, dc, GA);
-    gram_tables_kernel<NB><<<grid, 256, lds3, st>>>(S, K, GA, apow, c_same, dc, row_begin, row_end, ld);
-    e = hipGetLastError();
+    auto run = [&](auto rows_tag) -> hipError_t {
+      constexpr int R = decltype(rows_tag)::value;
+      const size_t lds3 = (size_t)(R * GramV3<NB>::PITCH + 4 * R) * sizeof(double);
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tables_kernel<NB, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      if (e1 != hipSuccess) return e1;
+      const long long first = row_begin & ~(long long)(R - 1);
+      dim3 grid((unsigned)((N + cols - 1) / cols), (unsigned)((row_end - first + R - 1) / R));
+      gram_tables_kernel<NB, R><<<grid, 256, lds3, st>>>(S, K, GA, apow, c_same, dc, row_begin, row_end, ld);
+      return hipGetLastError();
+    };
+    e = (rows64 || NB < 9) ? run(std::integral_constant<int, 64>{}) : run(std::integral_constant<int, 128>{});
     hipError_t e2 = hipFreeAsync(GA, st);
     return e != hipSuccess ? e : e2;
   }
