@@ -460,7 +460,11 @@ __device__ __forceinline__ void gram_tables_columns(const double* __restrict__ S
 #else
         if (!GUARD || (i >= row_begin && i < row_end))
 #endif
+#ifdef BORNVI_GRAM_PLAIN_STORE
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(rowp + (long long)(4 * r) * ld) + voff) = val;
+#else
           __builtin_nontemporal_store(val, reinterpret_cast<double*>(reinterpret_cast<char*>(rowp + (long long)(4 * r) * ld) + voff));
+#endif
       }
     }
     __builtin_amdgcn_wave_barrier();     // the scratch is rewritten by the next column tile
