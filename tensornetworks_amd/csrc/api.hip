@@ -517,6 +517,7 @@ int bornvi_create(int device_ordinal, bornvi_handle* out) {
   h->device = device_ordinal;
   // (A/B switches for whole test / bench runs; bornvi_set_option "reg_wires" / "read_map" are the per-handle form)
   if (const char* e = std::getenv("BORNVI_REG_WIRES")) { if (e[0] == '3' || e[0] == '4') h->opt.r = e[0] - '0'; }
+  if (const char* e = std::getenv("BORNVI_CONTIG_OUT")) h->opt.contig_out = e[0] != '0';
   if (const char* e = std::getenv("BORNVI_READ_MAP")) h->opt.read_map = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
@@ -566,6 +567,7 @@ int bornvi_set_option(bornvi_handle h, const char* name, long long value) {
   else if (!std::strcmp(name, "max_threads")) o.max_threads = (int)value;
   else if (!std::strcmp(name, "read_map")) o.read_map = value < 0 ? -1 : (value != 0 ? 1 : 0);   // -1: by the kernel (on with reg_wires = 3)
   else if (!std::strcmp(name, "reg_wires")) o.r = (int)value;
+  else if (!std::strcmp(name, "contig_out")) o.contig_out = value != 0;
   else return fail(h, BORNVI_ERR_INVALID, std::string("unknown option ") + name);
   if (o.kmax < 4 || o.kmax > 13 || (o.kmulti != 0 && (o.kmulti < 4 || o.kmulti > 13)) || o.lo < 0 || o.lo > 8 || o.max_threads < 64 || o.max_threads > 1024 ||
       (o.max_threads & (o.max_threads - 1)) || (o.r != 3 && o.r != 4))
@@ -583,6 +585,7 @@ int bornvi_get_option(bornvi_handle h, const char* name, long long* value) {
   else if (!std::strcmp(name, "tile_bits")) *value = h->opt.kmax;
   else if (!std::strcmp(name, "tile_bits_multi")) *value = h->opt.kmulti;
   else if (!std::strcmp(name, "low_bits")) *value = h->opt.lo;
+  else if (!std::strcmp(name, "contig_out")) *value = h->opt.contig_out;
   else if (!std::strcmp(name, "prefix_share")) *value = h->prefix_share;
   else if (!std::strcmp(name, "grad_engine")) *value = h->grad_engine;
   else if (!std::strcmp(name, "fast_path")) *value = h->fast_path;

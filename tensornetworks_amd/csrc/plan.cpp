@@ -521,6 +521,14 @@ bool build_plan(const BuildSpec& spec, const PlanOptions& opt, Plan& plan, std::
     if (i == np - 1) { for (int w = 0; w < n; ++w) layout[i][w] = n - 1 - w; continue; }
     int p = 0;
     for (int w : passes[i].out_low) layout[i][w] = p++;
+    if (opt.contig_out) {
+      // this pass's other local wires next: the ones the next pass keeps local first (its runs get longer), then the rest --
+      // a tile of this pass is then ONE contiguous block of the buffer
+      std::vector<char> nxt(n, 0);
+      for (int w : passes[i + 1].local) nxt[w] = 1;
+      for (int w : passes[i].local) if (layout[i][w] < 0 && nxt[w]) layout[i][w] = p++;
+      for (int w : passes[i].local) if (layout[i][w] < 0) layout[i][w] = p++;
+    }
     for (int w = 0; w < n; ++w) if (layout[i][w] < 0) layout[i][w] = p++;
   }
 

@@ -140,6 +140,12 @@ struct PlanOptions {
                      // eligible for the first)
   int lo = 6;        // contiguous low physical bits per HBM access (2^6 * 16 B = 1 KiB)
   int max_threads = 1024;
+  int contig_out = 1;      // physical layout of the buffer a pass writes: its OWN local wires on the low k bits (the wires it shares
+                           // with the next pass lowest), so that a tile is stored as one contiguous 2^k-amplitude block and the
+                           // next pass reads runs of 2^(shared wires).  0: only the `lo` shared wires are low, the rest in wire
+                           // order (both sides move 1-KiB runs).  Measured on the MI355X (tools/probes/tile_copy_probe.hip, the
+                           // tile traffic of a pass alone): both sides in 1-KiB runs 4.7 TB/s, contiguous stores + 1-KiB-run
+                           // loads 5.4 TB/s, the reverse 5.2 TB/s, both contiguous 5.8 TB/s.
   int read_map = -1;       // phase-0 CNOTs may target thread-held wires (general GF(2) read map, STAGE_CROSS_READ): fewer stages,
                            // but such a stage needs a barrier between its reads and its write-back.  Measured on the MI355X
                            // (n = 16 / 20): with 16 amplitudes per thread (8 waves in step per CU) the barrier costs more than
