@@ -81,7 +81,9 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
  * such a plan is eligible; 4: 16 amplitudes per thread, two waves per SIMD -- also the fallback; clears the plan cache),
  * "read_map" (default -1 = by the kernel: the planner may fold phase-0 CNOTs on thread-held wires into a stage's read map --
  * fewer stages, but such a stage needs a barrier between its reads and its write-back: faster with 8 amplitudes per
- * thread, slower with 16; 0 / 1 force it; clears the plan cache), "alternate_walk" (default 1: odd passes
+ * thread, slower with 16; 0 / 1 force it; clears the plan cache), "contig_out" (default 1: the buffer a pass writes keeps that
+ * pass's own local wires on its low address bits -- a tile is stored as one contiguous block, the next pass reads runs; 0: both
+ * sides move 1-KiB runs; clears the plan cache), "alternate_walk" (default 1: odd passes
  * walk the tiles of the batch from the last to the first, so that a pass starts on the states the previous one wrote last --
  * the ones the memory-side cache still holds), "batched_quadform" (0: bornvi_stein_quadform
  * with B > 1 runs B GEMV passes instead of one matrix-core pass); "grad_engine" (default 0 = the reference's
@@ -91,7 +93,7 @@ int bornvi_stream_destroy(bornvi_handle h, bornvi_stream stream);
  * its parameter touches instead of |0..0> -- the rows are bit-identical, fewer passes are run). */
 int bornvi_set_option(bornvi_handle h, const char* name, long long value);
 /* Current value of a planner / engine option ("reg_wires": 3 = the pass kernel with 8 amplitudes per thread and four waves
- * per SIMD where the plan is eligible, 4 = 16 per thread; "read_map", "tile_bits", "tile_bits_multi", "low_bits",
+ * per SIMD where the plan is eligible, 4 = 16 per thread; "read_map", "contig_out", "tile_bits", "tile_bits_multi", "low_bits",
  * "prefix_share", "grad_engine", "fast_path", "direct_stages", "zero_support", "alternate_walk", "batched_quadform"). */
 int bornvi_get_option(bornvi_handle h, const char* name, long long* value);
 
