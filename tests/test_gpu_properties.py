@@ -76,6 +76,28 @@ def test_gram_is_symmetric_psd_and_annihilates_the_posterior(n, seed, length_sca
 
 
 @settings(**SETTINGS)
+@given(st.integers(8, 11), st.integers(0, 10 ** 4), st.data())
+def test_gram_row_ranges_are_the_rows_of_the_full_matrix(n, seed, data):
+    """Any row range [r0, r1) of the matrix-core Gram builder, aligned to its 64-row blocks or not, with or without a padded
+    pitch: bit for bit the rows of the full matrix (the row shard of the contraction, and K_p's bitwise symmetry across
+    the ranks' blocks, rely on it), and nothing outside the range is written."""
+    be = _be()
+    N = 1 << n
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    S = (torch.rand((N, n), generator=g, dtype=torch.float64) * 2 - 1).to(DEV)
+    K = be.stein_gram(S, n, 1.0)
+    assert torch.equal(K, K.T)
+    r0 = data.draw(st.integers(0, N - 1))
+    r1 = data.draw(st.integers(r0, N))
+    pad = data.draw(st.sampled_from([0, 2, 32]))
+    buf = torch.full((r1 - r0 + 2, N + pad), -7.0, dtype=torch.float64, device=DEV)
+    out = buf[1:1 + (r1 - r0), :N]
+    be.stein_gram(S, n, 1.0, rows=(r0, r1), out=out)
+    assert torch.equal(out, K[r0:r1])
+    assert bool((buf[0] == -7.0).all()) and bool((buf[-1] == -7.0).all()) and (pad == 0 or bool((buf[:, N:] == -7.0).all()))
+
+
+@settings(**SETTINGS)
 @given(st.integers(2, 13), st.integers(0, 10 ** 4))
 def test_contraction_is_linear_and_its_forms_agree(n, seed):
     """K (a u + b v) = a K u + b K v for the symmetric, full-matrix and matrix-free contractions; q^T K q >= 0."""
