@@ -1,6 +1,7 @@
 """GPU parity of the drop-in classes (QuantumBornMachine, KSDVariationalInference) against the oracle's
 restatement of the reference epoch (ksd_vi_quantum.py:110-161)."""
 import io
+import os
 import contextlib
 import math
 
@@ -562,3 +563,14 @@ def test_second_train_keeps_the_gram_matrix_unless_the_scores_change(dev, capsys
     vi._prepare_stein(x)
     assert torch.equal(vi._K, K0)
     capsys.readouterr()
+
+
+def test_example_driver_runs(dev):
+    """examples/run_sprinkler_quantum_ksd.py -- the reference's run script on this engine -- end to end in a fresh process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "run_sprinkler_quantum_ksd.py"), "--epochs", "30", "--quiet"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Final TVD:" in out.stdout and "(1, 0, 1)" in out.stdout and "30 epochs in" in out.stdout
